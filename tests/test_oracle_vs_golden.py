@@ -43,7 +43,7 @@ def test_forward_and_loss(name):
     np.testing.assert_allclose(spk_preds.numpy(), case['out/speaker_preds'], rtol=0, atol=1e-5)
     np.testing.assert_allclose(film[3].numpy(), case['out/film_dec'], rtol=0, atol=1e-5)
     for k, v in internals.items():
-        np.testing.assert_allclose(v.numpy(), case['int/' + k], rtol=0, atol=2e-5, err_msg=k)
+        np.testing.assert_allclose(v.numpy(), case['int/' + k], rtol=5e-5, atol=2e-5, err_msg=k)
     assert abs(total.item() - float(case['loss/total'])) <= 1e-5 * abs(float(case['loss/total']))
     for k, v in terms.items():
         ref = float(case['loss/' + k])
