@@ -1,0 +1,112 @@
+/* C ABI of libdaft_exprt_hip.so: the gfx950 kernels behind the Daft-Exprt acoustic-model forward/backward path.
+ *
+ * The reference (claussss/ubisoft-laforge-daft-exprt) is pure Python/PyTorch and has no FFI of its own; each entry point
+ * below replaces the ATen work of one reference call site (cited per function, paths relative to
+ * src/daft_exprt/).  The Python host in ubisoft_laforge_daft_exprt_amd/ binds this file with ctypes; INTEGRATION.md shows
+ * the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch caching allocator); the library never allocates or frees
+ *   - activations are fp32, channels-last: a (B, N, C) tensor is [B*N] rows of C floats with a leading dimension (ld*)
+ *   - lens[b] (int32, device) = valid rows of batch row b; rows n >= lens[b] are padding
+ *   - `stream` is a hipStream_t; all work is enqueued on it, nothing synchronises (graph-capture safe)
+ *   - return value: 0 = ok, non-zero = error; dx_last_error() returns the message of the calling thread's last error
+ *   - dropout: counter-based (seed, element index); the backward entry points regenerate the mask from the same seed
+ */
+#ifndef DAFT_EXPRT_HIP_H
+#define DAFT_EXPRT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- runtime ----------------------------------------------------------------------------------------------------- */
+int dx_version(void);
+const char* dx_last_error(void);
+/* HIP-event bracketing of one kernel family (0 conv GEMM, 1 weight-grad GEMM, 2 attention fwd, 3 attention bwd,
+ * 4 upsampler fwd, 5 LayerNorm rows); used by bench.py to time the dominant kernel inside the timed region. */
+int dx_prof_enable(int kind, int capacity);
+int dx_prof_collect(int kind, int* launches, double* total_ms);
+
+/* ---- Conv1d / Linear as MFMA GEMM: model.py:57-72 (LinearNorm), :75-94 (ConvNorm1D), :165-186 (MHA in/out proj) ---- */
+/* dims[4] = {CoutP_fwd, CinP_fwd, CinP_bwd, CoutP_bwd}: padded sizes of the packed weights (element counts
+ * taps*dims[0]*dims[1] and taps*dims[2]*dims[3]); bf16 = 0 packs f32 (exact MFMA), 1 packs bf16 */
+int dx_pack_dims(int Cout, int Cin, int bf16, int* dims);
+/* W: checkpoint layout (Cout, Cin, taps) fp32 -> fwd pack [taps][CoutP][CinP], bwd pack (input-gradient conv) or NULL */
+int dx_pack_weights(const float* W, void* fwd, void* bwd, int Cout, int Cin, int taps, int bf16, void* stream);
+/* Y[b,n,:] = out_scale * mask( relu_aux>0 ? . : 0 )( post_scale * relu?( bias + conv(X) ) + post_shift )  (+= if accumulate)
+ * taps 1 (Linear) or 3 (zero 'same' padding inside each batch row).  NULL disables an epilogue stage. */
+int dx_conv_gemm(const float* X, int ldx, const void* Wp, const float* bias, float* Y, int ldy,
+                 int B, int N, int Cin, int Cout, int taps, int bf16,
+                 int relu, const float* post_scale, const float* post_shift,
+                 const float* relu_aux, int ld_aux, int accumulate,
+                 const int* lens, int mask_rows, float out_scale, void* stream);
+/* G[taps][Cout][Cin] (fp32, caller-zeroed) += dY^T * shifted X   (autograd of the conv w.r.t. its weight) */
+int dx_conv_wgrad(const float* dY, int ldy, const float* X, int ldx, float* G,
+                  int B, int N, int Cin, int Cout, int taps, void* stream);
+/* grad (Cout, Cin, taps) (+)= G[taps][Cout][Cin] */
+int dx_unpack_wgrad(const float* G, float* grad, int Cout, int Cin, int taps, int accumulate, void* stream);
+/* out[c] += sum_rows X[row][c]   (bias gradients) */
+int dx_colsum(const float* X, int ldx, float* out, long rows, int C, void* stream);
+
+/* ---- multi-head attention: model.py:165-186 (nn.MultiheadAttention slow path), called from :255 ------------------- */
+int dx_attention_fwd(const float* qkv, int ld, const int* lens, float* ctx, int ldc, float* lse,
+                     int B, int N, int H, int D, uint64_t seed, float p_drop, void* stream);
+int dx_attention_bwd(const float* qkv, int ld, const float* ctx, const float* dctx, int ldc, const float* lse, float* delta,
+                     const int* lens, float* dqkv, int ldg, int B, int N, int H, int D, uint64_t seed, float p_drop, void* stream);
+
+/* ---- dropout + residual + LayerNorm + FiLM + mask: model.py:188-191, :225-233, :256-258, :655-669 ------------------- */
+/* z = drop_pre(a) + res is written back over `a`; y = mask(film(drop_post(LN(z)))); C in {128, 1024} */
+int dx_ln_fwd(float* a, const float* res, const float* w, const float* bias, const float* film, int ld_film,
+              const int* lens, float* y, float* mean, float* rstd, int B, int N, int C,
+              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, void* stream);
+int dx_ln_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* w, const float* bias,
+              const float* film, int ld_film, const int* lens, float* dz, float* da, float* dw, float* dbias,
+              float* dfilm, int ld_dfilm, int B, int N, int C, int relu_mask,
+              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, void* stream);
+
+/* ---- embeddings, positions, masks, pooling: model.py:119-150, :597-604, :554-557, :687-716 --------------------------- */
+int dx_add_pos(const float* x, const long* sym, const float* emb, const float* pe, const int* lens, float* out,
+               int B, int N, int D, int pe_rows, void* stream);
+int dx_mask_rows(const float* in, const int* lens, float* out, int B, int N, int C, void* stream);
+int dx_embedding_bwd(const float* dout, const long* sym, const int* lens, float* demb, int B, int N, int D, void* stream);
+int dx_accent_sum(const float* prenet, const float* energy, const float* pitch, const float* we, const float* be,
+                  const float* wp, const float* bp, const float* pe, const int* lens, float* out,
+                  int B, int N, int D, int pe_rows, void* stream);
+int dx_scalar_conv_wgrad(const float* dout, int ldd, const float* rowscale, const float* s0, const float* s1, const int* lens,
+                         float* dw0, float* db0, float* dw1, float* db1, int B, int N, int D, void* stream);
+int dx_mean_pool(const float* x, const int* lens, float* out, int B, int N, int C, void* stream);
+int dx_mean_pool_bwd(const float* dout, const int* lens, float* dx, int B, int N, int C, void* stream);
+int dx_transpose(const float* in, float* out, int B, int R, int Cc, void* stream);
+int dx_l2_normalize(const float* x, float* y, int rows, int C, void* stream);            /* model.py:904 */
+int dx_cross_entropy(const float* logits, const long* target, float* loss, float* dlogits, int B, int S, void* stream); /* loss.py:85 */
+
+/* ---- Gaussian upsampling: model.py:417-510 ---------------------------------------------------------------------------- */
+int dx_duration_scan(const long* dur_int, float* mu, long* totals, int B, int L, void* stream);
+int dx_upsample_prep(const float* enc, const float* dur, const float* energy, const float* pitch,
+                     const float* wd, const float* bd, const float* we, const float* be, const float* wp, const float* bp,
+                     const float* wr, const float* br, const int* lens, float* xs, float* z, float* sigma,
+                     int B, int L, int D, void* stream);
+int dx_upsample_fwd(const float* xs, const float* mu, const float* sigma, const int* lens, float* weights, float* xup,
+                    int B, int L, int T, int D, void* stream);
+int dx_upsample_bwd(const float* dxup, const float* xs, const float* mu, const float* sigma, const float* weights, const int* lens,
+                    float* dxs, float* dsigma, int B, int L, int T, int D, void* stream);
+int dx_upsample_sym_bwd(const float* dxs_in, const float* dsigma, const float* xs, const float* z, const float* dur, const int* lens,
+                        const float* wd, const float* bd, const float* wr, float* dxs_out, float* dz, float* dwr, float* dbr,
+                        int B, int L, int D, void* stream);
+
+/* ---- loss reductions and gradients: loss.py:99-146 ------------------------------------------------------------------- */
+int dx_mel_stats(const float* mel_pred, const float* mel_target, float* ep, float* et, float* l1sum, float* l2sum,
+                 int B, int M, int T, void* stream);
+int dx_energy_diff(const float* ep, const float* et, const int* lens, float* des, float* esum, int B, int T, void* stream);
+int dx_mel_grad(const float* mel_pred, const float* mel_target, const float* ep, const float* des, const int* lens,
+                float c_l1, float c_l2, float c_e, float* dmel, int B, int M, int T, void* stream);
+int dx_pitch_mse(const float* pp, const float* gt, const int* lens, float* sums, int B, int T, void* stream);
+int dx_pitch_grad(const float* pp, const float* gt, const int* lens, const float* sums, float scale, float* dpp, int B, int T, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAFT_EXPRT_HIP_H */

@@ -1,0 +1,80 @@
+"""ctypes binding of libdaft_exprt_hip.so, generated from include/daft_exprt_hip.h.
+
+There is no CPU or PyTorch fallback: if the shared library is missing or an entry point fails, the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(PKG), 'include', 'daft_exprt_hip.h')
+LIB_PATH = os.path.join(PKG, 'libdaft_exprt_hip.so')
+
+_SCALARS = {'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float, 'double': ctypes.c_double,
+            'uint64_t': ctypes.c_uint64, 'uint32_t': ctypes.c_uint32}
+
+
+def parse_header(path: str = HEADER):
+    """-> {name: (restype, [argtypes])} for every function declared in the header."""
+    text = open(path).read()
+    text = re.sub(r'/\*.*?\*/', ' ', text, flags=re.S)
+    protos = {}
+    for ret, name, args in re.findall(r'\b(int|const char\*)\s+(dx_\w+)\s*\(([^)]*)\)\s*;', text):
+        argtypes = []
+        args = args.strip()
+        if args and args != 'void':
+            for a in args.split(','):
+                a = a.strip()
+                if '*' in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    base = a.replace('const ', '').split()[0]
+                    argtypes.append(_SCALARS[base])
+        protos[name] = (ctypes.c_int if ret == 'int' else ctypes.c_char_p, argtypes)
+    return protos
+
+
+class DxError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f'{LIB_PATH} is missing: build it with `python -m ubisoft_laforge_daft_exprt_amd.build` '
+                '(hipcc --offload-arch=gfx950). There is no fallback path.')
+        self._dll = ctypes.CDLL(LIB_PATH)
+        self._last_error = None
+        for name, (restype, argtypes) in parse_header().items():
+            fn = getattr(self._dll, name)  # AttributeError if the header and the library disagree
+            fn.restype = restype
+            fn.argtypes = argtypes
+            if name == 'dx_last_error':
+                self._last_error = fn
+                setattr(self, name, fn)
+            elif restype is ctypes.c_int and name != 'dx_version':
+                setattr(self, name, self._checked(name, fn))
+            else:
+                setattr(self, name, fn)
+
+    def _checked(self, name, fn):
+        def call(*args):
+            rc = fn(*args)
+            if rc != 0:
+                msg = self._last_error().decode(errors='replace') if self._last_error else ''
+                raise DxError(f'{name} failed (code {rc}): {msg}')
+        call.__name__ = name
+        return call
+
+
+_LIB = None
+
+
+def lib() -> _Lib:
+    global _LIB
+    if _LIB is None:
+        _LIB = _Lib()
+    return _LIB

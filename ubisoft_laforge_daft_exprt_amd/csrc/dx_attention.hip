@@ -1,0 +1,411 @@
+// Multi-head self-attention with key-padding mask and dropout on the probabilities, head_dim = 64, gfx950.
+// Replaces nn.MultiheadAttention's slow path as the reference calls it (src/daft_exprt/model.py:165-186, :255):
+// no (B*H, N, N) score matrix in HBM, no head-averaged weights (the caller discards them).
+//
+// Layout: qkv is the in-projection output, fp32 [B*N][3*D] (q | k | v, head h = columns h*64..h*64+63 of each third);
+// ctx is [B*N][D].  lse = log-sum-exp of the scaled, masked scores per (b, h, query) is kept for the backward.
+//
+// Forward / dQ kernels: a workgroup = 64 queries of one (b, h), 4 waves x 16 queries, looping over 64-key tiles in LDS.
+// Scores are computed TRANSPOSED, S^T = K Q^T (MFMA A = K rows from LDS, B = Q^T from registers), so a lane owns one
+// query column and 4 consecutive keys per 16x16 tile: the softmax statistics are per-lane scalars (+2 shuffles), and the
+// probability registers are already the MFMA B operand of O^T += V^T P^T (v_mfma_f32_16x16x4_f32, k = 4*lanegroup + reg):
+// no LDS round trip for P.  dK/dV kernel: a workgroup = 64 keys, 4 waves x 16 keys, looping over 64-query tiles; there the
+// scores are computed as S = Q K^T so that P / dS registers are the B operand of dV^T += dO^T P and dK^T += Q^T dS.
+// All accumulation is fp32; exp / log are the fp32 libm forms.
+#include "dx_common.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int HD = 64;       // head dim
+constexpr int TLD = 68;      // LDS row stride (floats) of a [64][64] tile: 16-B aligned rows, column reads conflict free
+constexpr float QSCALE = 0.125f;  // 1/sqrt(64), exact
+
+struct AttnArgs {
+  const float* qkv; int ld;        // [B*N][ld]
+  const int* lens;
+  float* ctx; int ldc;             // [B*N][ldc]
+  float* lse;                      // [B][H][N]
+  int B, N, H, D;
+  uint64_t seed; uint32_t thresh; float inv_keep;
+};
+
+__device__ __forceinline__ f32x4 mma4(const float4& a, const float4& b, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+  return c;
+}
+
+// stage rows [r0, r0+64) x 64 columns (starting at column col0) of a [B*N][ld] matrix into LDS; rows >= N are zero
+__device__ __forceinline__ void stage_tile(float* dst, const float* base, int ld, int col0, int r0, int N, int tid) {
+  for (int u = tid; u < 64 * 16; u += 256) {
+    const int row = u >> 4, q = u & 15;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + row < N) v = *reinterpret_cast<const float4*>(base + (size_t)(r0 + row) * ld + col0 + q * 4);
+    *reinterpret_cast<float4*>(dst + row * TLD + q * 4) = v;
+  }
+}
+
+__device__ __forceinline__ uint64_t drop_index(int bh, int N, int q, int key) {
+  return ((uint64_t)((size_t)bh * N + q) << 16) | (uint64_t)key;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float Ks[64 * TLD];
+  __shared__ __attribute__((aligned(16))) float Vs[64 * TLD];
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int len = a.lens[b];
+  const float* base = a.qkv + (size_t)b * a.N * a.ld;
+  const int qrow = q0 + wave * 16 + r;                 // this lane's query
+  float* out = a.ctx + ((size_t)b * a.N + qrow) * a.ldc + h * HD;
+  if (q0 >= len) {                                     // padded queries: defined zeros (they feed GEMMs later)
+    if (qrow < a.N) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<float4*>(out + dt * 16 + g * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g == 0) a.lse[((size_t)b * a.H + h) * a.N + qrow] = 0.f;
+    }
+    return;
+  }
+  const int qload = min(qrow, a.N - 1);
+  float4 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const float4 v = *reinterpret_cast<const float4*>(base + (size_t)qload * a.ld + h * HD + ks * 16 + g * 4);
+    qf[ks] = make_float4(v.x * QSCALE, v.y * QSCALE, v.z * QSCALE, v.w * QSCALE);
+  }
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const int bh = b * a.H + h;
+  const int ntiles = (len + 63) / 64;
+  for (int kt0 = 0; kt0 < ntiles; ++kt0) {
+    const int kbase = kt0 * 64;
+    __syncthreads();
+    stage_tile(Ks, base, a.ld, a.D + h * HD, kbase, a.N, tid);
+    stage_tile(Vs, base, a.ld, 2 * a.D + h * HD, kbase, a.N, tid);
+    __syncthreads();
+    f32x4 st[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const float4 kf = *reinterpret_cast<const float4*>(Ks + (kt * 16 + r) * TLD + ks * 16 + g * 4);
+        acc = mma4(kf, qf[ks], acc);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (kbase + kt * 16 + g * 4 + e >= len) acc[e] = -INFINITY;
+        mx = fmaxf(mx, acc[e]);
+      }
+      st[kt] = acc;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);              // finite: key 0 is always valid
+    const float alpha = expf(m_run - m_new);
+    float ls = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      float keep[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.thresh) dx_dropout_scale4(a.seed, drop_index(bh, a.N, qrow, kbase + kt * 16 + g * 4), a.thresh, a.inv_keep, keep);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p = expf(st[kt][e] - m_new);
+        ls += p;
+        st[kt][e] = p * keep[e];
+      }
+    }
+    ls += __shfl_xor(ls, 16, 64);
+    ls += __shfl_xor(ls, 32, 64);
+    l_run = l_run * alpha + ls;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4 acc = o[dt];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] *= alpha;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float vf = Vs[(kt * 16 + g * 4 + e) * TLD + dt * 16 + r];
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, st[kt][e], acc, 0, 0, 0);
+        }
+      }
+      o[dt] = acc;
+    }
+  }
+  if (qrow < a.N) {
+    const bool valid = qrow < len;
+    const float inv = valid ? 1.f / l_run : 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      *reinterpret_cast<float4*>(out + dt * 16 + g * 4) = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+    if (g == 0) a.lse[((size_t)b * a.H + h) * a.N + qrow] = valid ? m_run + logf(l_run) : 0.f;
+  }
+}
+
+// delta[b,h,q] = sum_d dctx[q][h*64+d] * ctx[q][h*64+d]     (wave per (row, head))
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ dctx, const float* __restrict__ ctx, int ldc,
+                                                         float* __restrict__ delta, int B, int N, int H) {
+  const int lane = threadIdx.x & 63;
+  const long items = (long)B * N * H;
+  for (long it = (long)blockIdx.x * 4 + (threadIdx.x >> 6); it < items; it += (long)gridDim.x * 4) {
+    const int h = (int)(it % H);
+    const long row = it / H;
+    const int b = (int)(row / N), n = (int)(row - (long)b * N);
+    const float v = dctx[row * ldc + h * HD + lane] * ctx[row * ldc + h * HD + lane];
+    const float s = dx_wave_sum(v);
+    if (lane == 0) delta[((size_t)b * H + h) * N + n] = s;
+  }
+}
+
+struct AttnBwdArgs {
+  const float* qkv; int ld;
+  const float* dctx; int ldc;
+  const float* lse; const float* delta;   // [B][H][N]
+  const int* lens;
+  float* dqkv; int ldg;                   // [B*N][ldg], same column layout as qkv
+  int B, N, H, D;
+  uint64_t seed; uint32_t thresh; float inv_keep;
+};
+
+// ------------------------------------------------------------------------------------------------
+// dQ: same geometry as the forward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float Ks[64 * TLD];
+  __shared__ __attribute__((aligned(16))) float Vs[64 * TLD];
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int len = a.lens[b];
+  const float* base = a.qkv + (size_t)b * a.N * a.ld;
+  const int qrow = q0 + wave * 16 + r;
+  float* out = a.dqkv + ((size_t)b * a.N + qrow) * a.ldg + h * HD;
+  if (q0 >= len) {
+    if (qrow < a.N) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<float4*>(out + dt * 16 + g * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
+  const int qload = min(qrow, a.N - 1);
+  const int bh = b * a.H + h;
+  float4 qf[4], gf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const float4 v = *reinterpret_cast<const float4*>(base + (size_t)qload * a.ld + h * HD + ks * 16 + g * 4);
+    qf[ks] = make_float4(v.x * QSCALE, v.y * QSCALE, v.z * QSCALE, v.w * QSCALE);
+    gf[ks] = *reinterpret_cast<const float4*>(a.dctx + ((size_t)b * a.N + qload) * a.ldc + h * HD + ks * 16 + g * 4);
+  }
+  const float lse_q = a.lse[(size_t)bh * a.N + qload];
+  const float delta_q = a.delta[(size_t)bh * a.N + qload];
+  f32x4 dq[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (len + 63) / 64;
+  for (int kt0 = 0; kt0 < ntiles; ++kt0) {
+    const int kbase = kt0 * 64;
+    __syncthreads();
+    stage_tile(Ks, base, a.ld, a.D + h * HD, kbase, a.N, tid);
+    stage_tile(Vs, base, a.ld, 2 * a.D + h * HD, kbase, a.N, tid);
+    __syncthreads();
+    f32x4 ds[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const float4 kf = *reinterpret_cast<const float4*>(Ks + (kt * 16 + r) * TLD + ks * 16 + g * 4);
+        const float4 vf = *reinterpret_cast<const float4*>(Vs + (kt * 16 + r) * TLD + ks * 16 + g * 4);
+        s = mma4(kf, qf[ks], s);
+        dp = mma4(vf, gf[ks], dp);
+      }
+      float keep[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.thresh) dx_dropout_scale4(a.seed, drop_index(bh, a.N, qrow, kbase + kt * 16 + g * 4), a.thresh, a.inv_keep, keep);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool masked = kbase + kt * 16 + g * 4 + e >= len;
+        const float p = masked ? 0.f : expf(s[e] - lse_q);
+        s[e] = p * (dp[e] * keep[e] - delta_q) * QSCALE;
+      }
+      ds[kt] = s;
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4 acc = dq[dt];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float kf = Ks[(kt * 16 + g * 4 + e) * TLD + dt * 16 + r];
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf, ds[kt][e], acc, 0, 0, 0);
+        }
+      }
+      dq[dt] = acc;
+    }
+  }
+  if (qrow < a.N) {
+    const float z = qrow < len ? 1.f : 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      *reinterpret_cast<float4*>(out + dt * 16 + g * 4) = make_float4(dq[dt][0] * z, dq[dt][1] * z, dq[dt][2] * z, dq[dt][3] * z);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dK, dV: workgroup = 64 keys of one (b, h); wave = 16 keys; loop over 64-query tiles
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float Qs[64 * TLD];
+  __shared__ __attribute__((aligned(16))) float Gs[64 * TLD];
+  __shared__ float lse_s[64], delta_s[64];
+  const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int len = a.lens[b];
+  const float* base = a.qkv + (size_t)b * a.N * a.ld;
+  const float* gbase = a.dctx + (size_t)b * a.N * a.ldc;
+  const int krow = k0 + wave * 16 + r;                 // this lane's key
+  float* outk = a.dqkv + ((size_t)b * a.N + krow) * a.ldg + a.D + h * HD;
+  float* outv = a.dqkv + ((size_t)b * a.N + krow) * a.ldg + 2 * a.D + h * HD;
+  if (k0 >= len) {
+    if (krow < a.N) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        *reinterpret_cast<float4*>(outk + dt * 16 + g * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(outv + dt * 16 + g * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    return;
+  }
+  const int kload = min(krow, a.N - 1);
+  const bool key_valid = krow < len;
+  const int bh = b * a.H + h;
+  float4 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const float4 v = *reinterpret_cast<const float4*>(base + (size_t)kload * a.ld + a.D + h * HD + ks * 16 + g * 4);
+    kf[ks] = make_float4(v.x * QSCALE, v.y * QSCALE, v.z * QSCALE, v.w * QSCALE);
+    vf[ks] = *reinterpret_cast<const float4*>(base + (size_t)kload * a.ld + 2 * a.D + h * HD + ks * 16 + g * 4);
+  }
+  f32x4 dk[4], dv[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const int ntiles = (len + 63) / 64;                  // queries >= len have zero upstream gradient
+  for (int qt0 = 0; qt0 < ntiles; ++qt0) {
+    const int qbase = qt0 * 64;
+    __syncthreads();
+    stage_tile(Qs, base, a.ld, h * HD, qbase, a.N, tid);
+    stage_tile(Gs, gbase, a.ldc, h * HD, qbase, a.N, tid);
+    if (tid < 64) {
+      const int q = qbase + tid;
+      lse_s[tid] = q < a.N ? a.lse[(size_t)bh * a.N + q] : 0.f;
+      delta_s[tid] = q < a.N ? a.delta[(size_t)bh * a.N + q] : 0.f;
+    }
+    __syncthreads();
+    f32x4 pd[4], ds[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const float4 qf = *reinterpret_cast<const float4*>(Qs + (qt * 16 + r) * TLD + ks * 16 + g * 4);
+        const float4 gf = *reinterpret_cast<const float4*>(Gs + (qt * 16 + r) * TLD + ks * 16 + g * 4);
+        s = mma4(qf, kf[ks], s);
+        dp = mma4(gf, vf[ks], dp);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ql = qt * 16 + g * 4 + e, q = qbase + ql;
+        const bool live = key_valid && q < len;
+        const float p = live ? expf(s[e] - lse_s[ql]) : 0.f;
+        float keep = 1.f;
+        if (a.thresh) keep = dx_dropout_scale(a.seed, drop_index(bh, a.N, q, krow), a.thresh, a.inv_keep);
+        pd[qt][e] = p * keep;
+        ds[qt][e] = p * (dp[e] * keep - delta_s[ql]) * QSCALE;
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4 accv = dv[dt], acck = dk[dt];
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float gcol = Gs[(qt * 16 + g * 4 + e) * TLD + dt * 16 + r];
+          const float qcol = Qs[(qt * 16 + g * 4 + e) * TLD + dt * 16 + r];
+          accv = __builtin_amdgcn_mfma_f32_16x16x4f32(gcol, pd[qt][e], accv, 0, 0, 0);
+          acck = __builtin_amdgcn_mfma_f32_16x16x4f32(qcol, ds[qt][e], acck, 0, 0, 0);
+        }
+      }
+      dv[dt] = accv; dk[dt] = acck;
+    }
+  }
+  if (krow < a.N) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      *reinterpret_cast<float4*>(outk + dt * 16 + g * 4) = make_float4(dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]);
+      *reinterpret_cast<float4*>(outv + dt * 16 + g * 4) = make_float4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
+    }
+  }
+}
+
+int check_common(const char* who, const void* qkv, int ld, int B, int N, int H, int D) {
+  DX_REQUIRE(qkv != nullptr, "%s: null pointer", who);
+  DX_REQUIRE(B > 0 && N > 0 && H > 0 && D == H * HD, "%s: head dim must be 64 (D=%d, H=%d)", who, D, H);
+  DX_REQUIRE(ld >= 3 * D && (ld % 4) == 0 && ((uintptr_t)qkv % 16) == 0, "%s: qkv must be 16-byte aligned with ld >= 3*D, ld %% 4 == 0", who);
+  DX_REQUIRE(N < 65536, "%s: sequence length %d too long", who, N);
+  return DX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dx_attention_fwd(const float* qkv, int ld, const int* lens, float* ctx, int ldc, float* lse,
+                     int B, int N, int H, int D, uint64_t seed, float p_drop, void* stream) {
+  if (int rc = check_common("dx_attention_fwd", qkv, ld, B, N, H, D)) return rc;
+  DX_REQUIRE(lens && ctx && lse && ldc >= D && (ldc % 4) == 0 && ((uintptr_t)ctx % 16) == 0, "dx_attention_fwd: bad output arguments");
+  DX_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "dx_attention_fwd: dropout p out of range");
+  AttnArgs a{qkv, ld, lens, ctx, ldc, lse, B, N, H, D, seed, (uint32_t)lrintf(p_drop * 65536.f), 1.f / (1.f - p_drop)};
+  hipStream_t s = (hipStream_t)stream;
+  dx_prof_begin(DX_PROF_ATTN_FWD, s);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
+  dx_prof_end(DX_PROF_ATTN_FWD, s);
+  DX_LAUNCH_CHECK("dx_attention_fwd");
+  return DX_OK;
+}
+
+// dqkv (all three thirds, every row) from dctx; `delta` is scratch [B][H][N]
+int dx_attention_bwd(const float* qkv, int ld, const float* ctx, const float* dctx, int ldc, const float* lse, float* delta,
+                     const int* lens, float* dqkv, int ldg, int B, int N, int H, int D, uint64_t seed, float p_drop, void* stream) {
+  if (int rc = check_common("dx_attention_bwd", qkv, ld, B, N, H, D)) return rc;
+  DX_REQUIRE(ctx && dctx && lse && delta && lens && dqkv, "dx_attention_bwd: null pointer");
+  DX_REQUIRE(ldc >= D && (ldc % 4) == 0 && ldg >= 3 * D && (ldg % 4) == 0, "dx_attention_bwd: bad leading dimensions");
+  DX_REQUIRE(((uintptr_t)dctx % 16) == 0 && ((uintptr_t)dqkv % 16) == 0, "dx_attention_bwd: pointers must be 16-byte aligned");
+  DX_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "dx_attention_bwd: dropout p out of range");
+  hipStream_t s = (hipStream_t)stream;
+  const long items = (long)B * N * H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((int)std::min<long>((items + 3) / 4, 8192)), dim3(256), 0, s, dctx, ctx, ldc, delta, B, N, H);
+  AttnBwdArgs a{qkv, ld, dctx, ldc, lse, delta, lens, dqkv, ldg, B, N, H, D, seed, (uint32_t)lrintf(p_drop * 65536.f), 1.f / (1.f - p_drop)};
+  dx_prof_begin(DX_PROF_ATTN_BWD, s);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
+  dx_prof_end(DX_PROF_ATTN_BWD, s);
+  DX_LAUNCH_CHECK("dx_attention_bwd");
+  return DX_OK;
+}
+
+}  // extern "C"

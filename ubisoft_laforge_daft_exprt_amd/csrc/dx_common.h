@@ -1,0 +1,83 @@
+// Shared device/host helpers for the Daft-Exprt gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define DX_OK 0
+#define DX_ERR_ARG 1
+#define DX_ERR_LAUNCH 2
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+void dx_set_error(const char* fmt, ...);
+void dx_prof_begin(int kernel_id, hipStream_t s);
+void dx_prof_end(int kernel_id, hipStream_t s);
+#ifdef __cplusplus
+}
+#endif
+
+#define DX_REQUIRE(cond, ...)              \
+  do {                                     \
+    if (!(cond)) {                         \
+      dx_set_error(__VA_ARGS__);           \
+      return DX_ERR_ARG;                   \
+    }                                      \
+  } while (0)
+
+#define DX_LAUNCH_CHECK(name)                                         \
+  do {                                                                \
+    hipError_t e_ = hipGetLastError();                                \
+    if (e_ != hipSuccess) {                                           \
+      dx_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+      return DX_ERR_LAUNCH;                                           \
+    }                                                                 \
+  } while (0)
+
+// kernel families that can be bracketed by HIP events (bench.py roofline leg)
+enum { DX_PROF_CONV_GEMM = 0, DX_PROF_WGRAD_GEMM = 1, DX_PROF_ATTN_FWD = 2, DX_PROF_ATTN_BWD = 3,
+       DX_PROF_UPSAMPLE = 4, DX_PROF_ROWS = 5, DX_PROF_NKINDS = 6 };
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+static inline int dx_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int dx_roundup(int a, int b) { return dx_cdiv(a, b) * b; }
+
+#ifdef __HIPCC__
+// ---- wave64 reductions -------------------------------------------------------------------------
+__device__ __forceinline__ float dx_wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float dx_wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// ---- counter-based dropout RNG -----------------------------------------------------------------
+// splitmix64 of (seed, index): 64 random bits = four 16-bit keep/drop decisions.  The same (seed, index)
+// is evaluated again in the backward kernels, so no mask tensor is stored.
+__device__ __forceinline__ uint64_t dx_rand64(uint64_t seed, uint64_t idx) {
+  uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+// keep-scale for element `elem` (linear index in its tensor): 0 or 1/(1-p).  thresh16 = round(p * 65536).
+__device__ __forceinline__ float dx_dropout_scale(uint64_t seed, uint64_t elem, uint32_t thresh16, float inv_keep) {
+  uint64_t r = dx_rand64(seed, elem >> 2);
+  uint32_t bits = (uint32_t)(r >> (16 * (elem & 3))) & 0xFFFFu;
+  return bits >= thresh16 ? inv_keep : 0.0f;
+}
+// four consecutive elements (elem0 % 4 == 0)
+__device__ __forceinline__ void dx_dropout_scale4(uint64_t seed, uint64_t elem0, uint32_t thresh16, float inv_keep, float out[4]) {
+  uint64_t r = dx_rand64(seed, elem0 >> 2);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[i] = ((uint32_t)(r >> (16 * i)) & 0xFFFFu) >= thresh16 ? inv_keep : 0.0f;
+}
+#endif

@@ -1,0 +1,457 @@
+// Conv1D(k=1|3, stride 1, zero 'same' padding) on channels-last activations as an MFMA GEMM, gfx950.
+//
+// Replaces the reference's ConvNorm1D / LinearNorm / in_proj / out_proj call sites
+// (src/daft_exprt/model.py:57-94, :165-186, :206-217, :649-671) and their autograd backward.
+//
+//   forward      Y[b,n,co]  = epi( bias[co] + sum_tap sum_ci X[b, n+tap-PAD, ci] * W[co,ci,tap] )
+//   input grad   the same kernel fed with the flipped/transposed pack of W
+//   weight grad  G[tap][co][ci] += sum_{b,n} dY[b,n,co] * X[b, n+tap-PAD, ci]      (split over tokens, fp32 atomics)
+//
+// Data layout in HBM: activations are fp32 [B*N][C] (channels contiguous).  Weights are re-packed once per
+// optimiser step from the checkpoint layout (Cout, Cin, TAPS) into [TAPS][CoutP][CinP] with Cin contiguous
+// (CoutP, CinP = dims rounded up to the tile, zero filled), as f32 (exact-f32 MFMA, v_mfma_f32_16x16x4_f32)
+// or bf16 (v_mfma_f32_16x16x32_bf16, fp32 accumulate).
+//
+// Tiling (wave64, 4 waves = 2x2 per workgroup): a workgroup owns 128 output channels x 128 tokens of ONE
+// batch row; a wave owns 64x64 as 4x4 MFMA tiles of 16x16.  W is the MFMA "A" operand (rows = channels),
+// X the "B" operand (columns = tokens), so every lane ends up with 4 consecutive output channels of one
+// token: 16-byte stores, and per-channel epilogue vectors are 16-byte loads.  Both operands sit in LDS as
+// [row][128 bytes of K] (+16 B pad); a lane fetches its whole fragment for 16 (f32) / 32 (bf16) K values
+// with one ds_read_b128.  For f32 the K index inside a 16-wide group is permuted (lane group g, element j
+// <-> k = 4g + j) identically for both operands, which leaves the sum unchanged.
+// The token tile is staged once per K chunk WITH a one-row halo on both sides; the three taps read it at
+// row offsets 0/1/2, so X is fetched once, not three times.  Rows outside [0, N) of the batch row are
+// zero, which is exactly the reference's zero 'same' padding on the padded (B, N_max) grid.
+#include "dx_common.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int TILE = 128;   // channels and tokens per workgroup
+constexpr int ROWB = 144;   // LDS row stride in bytes: 128 B of K + 16 B pad
+
+struct ConvGemmArgs {
+  const float* X; int ldx;
+  const void* Wp;
+  const float* bias;
+  float* Y; int ldy;
+  int B, N, Cin, Cout, CinP, CoutP;
+  int relu;
+  const float* post_scale; const float* post_shift;
+  const float* relu_aux; int ld_aux;
+  int accumulate;
+  const int* lens; int mask_rows;
+  float out_scale;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+  static __device__ __forceinline__ void run(const float4& a, const float4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<__bf16> {
+  static __device__ __forceinline__ void run(const float4& a, const float4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ uint2 pack_bf16x4(const float4& v) {
+  bf16x4 h;
+  h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+  return __builtin_bit_cast(uint2, h);
+}
+
+template <typename T, int TAPS>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a) {
+  constexpr int PAD = (TAPS - 1) / 2;
+  constexpr int BK = 128 / (int)sizeof(T);
+  constexpr int XROWS = TILE + TAPS - 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ws = smem;
+  unsigned char* Xs = smem + TAPS * TILE * ROWB;
+
+  const int tiles_n = (a.N + TILE - 1) / TILE;
+  const int b = blockIdx.x / tiles_n;
+  const int n0 = (blockIdx.x - b * tiles_n) * TILE;
+  const int co0 = blockIdx.y * TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave >> 1, wt = wave & 1;
+  const int r = lane & 15, g = lane >> 4;
+  const T* Wp = reinterpret_cast<const T*>(a.Wp);
+  const float* Xb = a.X + (size_t)b * a.N * a.ldx;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = a.CinP / BK;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int ci0 = ch * BK;
+    __syncthreads();
+    // weights: TAPS*128 rows x 8 sixteen-byte units, no bounds (the pack is zero padded)
+    for (int u = tid; u < TAPS * TILE * 8; u += 256) {
+      const int row = u >> 3, q = u & 7;
+      const int tap = row >> 7, col = row & (TILE - 1);
+      const T* src = Wp + ((size_t)(tap * a.CoutP + co0 + col) * a.CinP + ci0) + q * (16 / (int)sizeof(T));
+      *reinterpret_cast<float4*>(Ws + row * ROWB + q * 16) = *reinterpret_cast<const float4*>(src);
+    }
+    // activations with halo rows; zero outside the batch row / beyond Cin
+    if constexpr (sizeof(T) == 4) {
+      for (int u = tid; u < XROWS * 8; u += 256) {
+        const int row = u >> 3, q = u & 7;
+        const int n = n0 + row - PAD, ci = ci0 + q * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n >= 0 && n < a.N && ci < a.Cin) v = *reinterpret_cast<const float4*>(Xb + (size_t)n * a.ldx + ci);
+        *reinterpret_cast<float4*>(Xs + row * ROWB + q * 16) = v;
+      }
+    } else {
+      for (int u = tid; u < XROWS * 16; u += 256) {
+        const int row = u >> 4, q = u & 15;
+        const int n = n0 + row - PAD, ci = ci0 + q * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n >= 0 && n < a.N && ci < a.Cin) v = *reinterpret_cast<const float4*>(Xb + (size_t)n * a.ldx + ci);
+        *reinterpret_cast<uint2*>(Xs + row * ROWB + q * 8) = pack_bf16x4(v);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        float4 wf[4], xf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          wf[i] = *reinterpret_cast<const float4*>(Ws + (tap * TILE + wc * 64 + i * 16 + r) * ROWB + ks * 64 + g * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          xf[j] = *reinterpret_cast<const float4*>(Xs + (wt * 64 + j * 16 + r + tap) * ROWB + ks * 64 + g * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
+      }
+    }
+  }
+
+  // epilogue: lane holds channels co..co+3 of token n
+  const int len_b = a.lens ? a.lens[b] : a.N;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int co = co0 + wc * 64 + i * 16 + g * 4;
+    if (co >= a.Cout) continue;
+    const bool full = (co + 3 < a.Cout);
+    float bv[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (co + e < a.Cout) {
+        if (a.bias) bv[e] = a.bias[co + e];
+        if (a.post_scale) { sc[e] = a.post_scale[co + e]; sh[e] = a.post_shift[co + e]; }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wt * 64 + j * 16 + r;
+      if (n >= a.N) continue;
+      const size_t row = (size_t)b * a.N + n;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = acc[i][j][e] + bv[e];
+        if (a.relu) t = fmaxf(t, 0.f);
+        t = t * sc[e] + sh[e];
+        v[e] = t * a.out_scale;
+      }
+      if (a.relu_aux) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (co + e < a.Cout && !(a.relu_aux[row * a.ld_aux + co + e] > 0.f)) v[e] = 0.f;
+      }
+      if (a.mask_rows && n >= len_b) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+      float* dst = a.Y + row * a.ldy + co;
+      if (full) {
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (a.accumulate) {
+          const float4 old = *reinterpret_cast<const float4*>(dst);
+          o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+        }
+        *reinterpret_cast<float4*>(dst) = o;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (co + e < a.Cout) dst[e] = a.accumulate ? dst[e] + v[e] : v[e];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient: G[tap][co][ci] += sum over tokens of dY[token][co] * X[token + tap - PAD][ci]
+// Both operands are token-major in HBM, i.e. K-major; they are staged untransposed ([token][channel],
+// row stride 132 floats) and fragments are gathered with four ds_read_b32 per operand (conflict free:
+// lanes 0-15 read consecutive channels, lane groups sit 4 rows = 16 banks apart).
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* dY; int ldy;
+  const float* X; int ldx;
+  float* G;
+  int B, N, Cin, Cout, ksplit;
+};
+
+constexpr int WG_BK = 32;     // tokens per K chunk
+constexpr int WG_LD = 132;    // LDS row stride in floats
+
+template <int TAPS>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
+  constexpr int PAD = (TAPS - 1) / 2;
+  __shared__ __attribute__((aligned(16))) float Ds[WG_BK * WG_LD];
+  __shared__ __attribute__((aligned(16))) float Xs[(WG_BK + 2) * WG_LD];
+  const int ci_tiles = (a.Cin + TILE - 1) / TILE;
+  const int co0 = (blockIdx.x / ci_tiles) * TILE;
+  const int ci0 = (blockIdx.x % ci_tiles) * TILE;
+  const int tap = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave >> 1, wt = wave & 1;
+  const int r = lane & 15, g = lane >> 4;
+
+  const int chunks_per_row = (a.N + WG_BK - 1) / WG_BK;
+  const int total = a.B * chunks_per_row;
+  const int per = (total + a.ksplit - 1) / a.ksplit;
+  const int c_begin = blockIdx.z * per;
+  const int c_end = min(total, c_begin + per);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int c = c_begin; c < c_end; ++c) {
+    const int b = c / chunks_per_row;
+    const int nc = (c - b * chunks_per_row) * WG_BK;
+    const float* dYb = a.dY + (size_t)b * a.N * a.ldy;
+    const float* Xb = a.X + (size_t)b * a.N * a.ldx;
+    __syncthreads();
+    for (int u = tid; u < WG_BK * 32; u += 256) {
+      const int row = u >> 5, q = u & 31;
+      const int n = nc + row, co = co0 + q * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < a.N && co < a.Cout) v = *reinterpret_cast<const float4*>(dYb + (size_t)n * a.ldy + co);
+      *reinterpret_cast<float4*>(&Ds[row * WG_LD + q * 4]) = v;
+    }
+    for (int u = tid; u < (WG_BK + TAPS - 1) * 32; u += 256) {
+      const int row = u >> 5, q = u & 31;
+      const int n = nc + row - PAD, ci = ci0 + q * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n >= 0 && n < a.N && ci < a.Cin) v = *reinterpret_cast<const float4*>(Xb + (size_t)n * a.ldx + ci);
+      *reinterpret_cast<float4*>(&Xs[row * WG_LD + q * 4]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kg = 0; kg < WG_BK / 16; ++kg) {
+      float df[4][4], xf[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) df[i][e] = Ds[(kg * 16 + g * 4 + e) * WG_LD + wc * 64 + i * 16 + r];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xf[j][e] = Xs[(kg * 16 + g * 4 + e + tap) * WG_LD + wt * 64 + j * 16 + r];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(df[i][e], xf[j][e], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ci = ci0 + wt * 64 + j * 16 + r;
+      if (ci >= a.Cin) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = co0 + wc * 64 + i * 16 + g * 4 + e;
+        if (co < a.Cout) atomicAdd(&a.G[((size_t)tap * a.Cout + co) * a.Cin + ci], acc[i][j][e]);
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// packing: checkpoint layout (Cout, Cin, TAPS) fp32 -> fwd [TAPS][CoutP][CinP], bwd [TAPS][CinPo][CoutPi]
+// (bwd = transposed channels, flipped taps: the input-gradient conv).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ W, T* __restrict__ fwd, T* __restrict__ bwd,
+                                    int Cout, int Cin, int taps, int CoutP_f, int CinP_f, int CinP_b, int CoutP_b) {
+  const size_t nf = (size_t)taps * CoutP_f * CinP_f;
+  const size_t nb = bwd ? (size_t)taps * CinP_b * CoutP_b : 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nb; i += (size_t)gridDim.x * blockDim.x) {
+    if (i < nf) {
+      const int ci = (int)(i % CinP_f);
+      const int co = (int)((i / CinP_f) % CoutP_f);
+      const int tap = (int)(i / ((size_t)CinP_f * CoutP_f));
+      const float v = (co < Cout && ci < Cin) ? W[((size_t)co * Cin + ci) * taps + tap] : 0.f;
+      fwd[i] = (T)v;
+    } else {
+      const size_t k = i - nf;
+      const int co = (int)(k % CoutP_b);
+      const int ci = (int)((k / CoutP_b) % CinP_b);
+      const int tap = (int)(k / ((size_t)CoutP_b * CinP_b));
+      const float v = (co < Cout && ci < Cin) ? W[((size_t)co * Cin + ci) * taps + (taps - 1 - tap)] : 0.f;
+      bwd[k] = (T)v;
+    }
+  }
+}
+
+// grad[co][ci][tap] (+)= G[tap][co][ci]
+__global__ void unpack_wgrad_kernel(const float* __restrict__ G, float* __restrict__ grad, int Cout, int Cin, int taps, int accumulate) {
+  const size_t n = (size_t)Cout * Cin * taps;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % taps);
+    const size_t cc = i / taps;
+    const float v = G[(size_t)tap * Cout * Cin + cc];
+    grad[i] = accumulate ? grad[i] + v : v;
+  }
+}
+
+// column sums: out[c] += sum_rows X[row][c]   (bias gradients)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int ldx, float* __restrict__ out,
+                                                     long rows, int C, int rows_per_block) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  const long r1 = min(rows, r0 + rows_per_block);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  long rr = r0;
+  for (; rr + 3 < r1; rr += 4) {
+    s0 += X[(size_t)rr * ldx + c];
+    s1 += X[(size_t)(rr + 1) * ldx + c];
+    s2 += X[(size_t)(rr + 2) * ldx + c];
+    s3 += X[(size_t)(rr + 3) * ldx + c];
+  }
+  for (; rr < r1; ++rr) s0 += X[(size_t)rr * ldx + c];
+  atomicAdd(&out[c], (s0 + s1) + (s2 + s3));
+}
+
+template <typename T, int TAPS>
+int launch_conv(const ConvGemmArgs& a, hipStream_t s) {
+  const size_t smem = (size_t)(TAPS * TILE + TILE + TAPS - 1) * ROWB;
+  static bool configured = false;
+  if (!configured) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    configured = true;
+  }
+  dim3 grid(a.B * dx_cdiv(a.N, TILE), a.CoutP / TILE);
+  hipLaunchKernelGGL((conv_gemm_kernel<T, TAPS>), grid, dim3(256), smem, s, a);
+  return DX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Packed-weight geometry for a (Cout, Cin, taps) layer at operand precision `bf16` (0: f32, 1: bf16).
+// Returns element counts so the caller can allocate; dims: [CoutP_f, CinP_f, CinP_b, CoutP_b].
+int dx_pack_dims(int Cout, int Cin, int bf16, int* dims) {
+  const int bk = bf16 ? 64 : 32;
+  dims[0] = dx_roundup(Cout, TILE);
+  dims[1] = dx_roundup(Cin, bk);
+  dims[2] = dx_roundup(Cin, TILE);
+  dims[3] = dx_roundup(Cout, bk);
+  return DX_OK;
+}
+
+int dx_pack_weights(const float* W, void* fwd, void* bwd, int Cout, int Cin, int taps, int bf16, void* stream) {
+  DX_REQUIRE(W && fwd, "dx_pack_weights: null pointer");
+  DX_REQUIRE(Cout > 0 && Cin > 0 && (taps == 1 || taps == 3), "dx_pack_weights: bad dims Cout=%d Cin=%d taps=%d", Cout, Cin, taps);
+  int d[4];
+  dx_pack_dims(Cout, Cin, bf16, d);
+  const size_t n = (size_t)taps * d[0] * d[1] + (bwd ? (size_t)taps * d[2] * d[3] : 0);
+  const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+  hipStream_t s = (hipStream_t)stream;
+  if (bf16)
+    hipLaunchKernelGGL(pack_weights_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, W, (__bf16*)fwd, (__bf16*)bwd, Cout, Cin, taps, d[0], d[1], d[2], d[3]);
+  else
+    hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, s, W, (float*)fwd, (float*)bwd, Cout, Cin, taps, d[0], d[1], d[2], d[3]);
+  DX_LAUNCH_CHECK("dx_pack_weights");
+  return DX_OK;
+}
+
+// Y = epilogue(conv(X, Wp) + bias).  See ConvGemmArgs for the epilogue switches.
+int dx_conv_gemm(const float* X, int ldx, const void* Wp, const float* bias, float* Y, int ldy,
+                 int B, int N, int Cin, int Cout, int taps, int bf16,
+                 int relu, const float* post_scale, const float* post_shift,
+                 const float* relu_aux, int ld_aux, int accumulate,
+                 const int* lens, int mask_rows, float out_scale, void* stream) {
+  DX_REQUIRE(X && Wp && Y, "dx_conv_gemm: null pointer");
+  DX_REQUIRE(B > 0 && N > 0 && Cin > 0 && Cout > 0, "dx_conv_gemm: bad dims B=%d N=%d Cin=%d Cout=%d", B, N, Cin, Cout);
+  DX_REQUIRE(taps == 1 || taps == 3, "dx_conv_gemm: taps must be 1 or 3 (got %d)", taps);
+  DX_REQUIRE((Cin % 4) == 0 && (ldx % 4) == 0 && ldx >= Cin, "dx_conv_gemm: Cin (%d) and ldx (%d) must be multiples of 4, ldx >= Cin", Cin, ldx);
+  DX_REQUIRE(ldy >= Cout && ((Cout % 4) != 0 || (ldy % 4) == 0), "dx_conv_gemm: bad ldy %d for Cout %d", ldy, Cout);
+  DX_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)Wp % 16) == 0 && ((uintptr_t)Y % 16) == 0, "dx_conv_gemm: pointers must be 16-byte aligned");
+  DX_REQUIRE(!relu_aux || ld_aux >= Cout, "dx_conv_gemm: bad ld_aux");
+  DX_REQUIRE((post_scale == nullptr) == (post_shift == nullptr), "dx_conv_gemm: post_scale/post_shift must come together");
+  DX_REQUIRE(!mask_rows || lens, "dx_conv_gemm: mask_rows needs lens");
+  int d[4];
+  dx_pack_dims(Cout, Cin, bf16, d);
+  ConvGemmArgs a{X, ldx, Wp, bias, Y, ldy, B, N, Cin, Cout, d[1], d[0], relu, post_scale, post_shift,
+                 relu_aux, ld_aux, accumulate, lens, mask_rows, out_scale};
+  hipStream_t s = (hipStream_t)stream;
+  dx_prof_begin(DX_PROF_CONV_GEMM, s);
+  if (bf16) { if (taps == 3) launch_conv<__bf16, 3>(a, s); else launch_conv<__bf16, 1>(a, s); }
+  else      { if (taps == 3) launch_conv<float, 3>(a, s);  else launch_conv<float, 1>(a, s); }
+  dx_prof_end(DX_PROF_CONV_GEMM, s);
+  DX_LAUNCH_CHECK("dx_conv_gemm");
+  return DX_OK;
+}
+
+// G[taps][Cout][Cin] (fp32, caller-zeroed) += dY^T * shift(X); then dx_unpack_wgrad moves it to (Cout, Cin, taps).
+int dx_conv_wgrad(const float* dY, int ldy, const float* X, int ldx, float* G,
+                  int B, int N, int Cin, int Cout, int taps, void* stream) {
+  DX_REQUIRE(dY && X && G, "dx_conv_wgrad: null pointer");
+  DX_REQUIRE(B > 0 && N > 0 && Cin > 0 && Cout > 0 && (taps == 1 || taps == 3), "dx_conv_wgrad: bad dims");
+  DX_REQUIRE((Cin % 4) == 0 && (ldx % 4) == 0 && (Cout % 4) == 0 && (ldy % 4) == 0, "dx_conv_wgrad: Cin/Cout/ld must be multiples of 4 (Cin=%d Cout=%d)", Cin, Cout);
+  DX_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)dY % 16) == 0, "dx_conv_wgrad: pointers must be 16-byte aligned");
+  const int tiles = dx_cdiv(Cout, TILE) * dx_cdiv(Cin, TILE);
+  const int total_chunks = B * dx_cdiv(N, WG_BK);
+  int ksplit = std::max(1, std::min(total_chunks, dx_cdiv(1024, tiles * taps)));
+  WgradArgs a{dY, ldy, X, ldx, G, B, N, Cin, Cout, ksplit};
+  hipStream_t s = (hipStream_t)stream;
+  dx_prof_begin(DX_PROF_WGRAD_GEMM, s);
+  if (taps == 3) hipLaunchKernelGGL(wgrad_kernel<3>, dim3(tiles, taps, ksplit), dim3(256), 0, s, a);
+  else           hipLaunchKernelGGL(wgrad_kernel<1>, dim3(tiles, taps, ksplit), dim3(256), 0, s, a);
+  dx_prof_end(DX_PROF_WGRAD_GEMM, s);
+  DX_LAUNCH_CHECK("dx_conv_wgrad");
+  return DX_OK;
+}
+
+int dx_unpack_wgrad(const float* G, float* grad, int Cout, int Cin, int taps, int accumulate, void* stream) {
+  DX_REQUIRE(G && grad && Cout > 0 && Cin > 0 && taps > 0, "dx_unpack_wgrad: bad arguments");
+  const size_t n = (size_t)Cout * Cin * taps;
+  const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, G, grad, Cout, Cin, taps, accumulate);
+  DX_LAUNCH_CHECK("dx_unpack_wgrad");
+  return DX_OK;
+}
+
+// out[c] += sum_rows X[row][c]; out is caller-initialised (bias gradients).
+int dx_colsum(const float* X, int ldx, float* out, long rows, int C, void* stream) {
+  DX_REQUIRE(X && out && rows > 0 && C > 0 && ldx >= C, "dx_colsum: bad arguments");
+  const int rpb = 256;
+  dim3 grid(dx_cdiv(C, 256), (unsigned)((rows + rpb - 1) / rpb));
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, out, rows, C, rpb);
+  DX_LAUNCH_CHECK("dx_colsum");
+  return DX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,550 @@
+// Memory-bound row kernels (one wave64 per token row, 16-byte / 8-byte coalesced accesses):
+//   * residual + dropout + LayerNorm + FiLM + padding mask, forward and backward
+//       (reference: model.py:188-191, :225-233, :256-258, prenet LayerNorms :655-669)
+//   * symbol embedding + sinusoidal position + mask (model.py:597-604), decoder input (model.py:554-557)
+//   * accent-encoder input sum: prenet + Conv1d(1->D) energy + Conv1d(1->D) pitch + position, masked (model.py:687-706)
+//   * masked mean pooling (model.py:714), batched transposes, row L2-normalise (model.py:904), cross entropy (loss.py:85)
+// All HBM-bound: the roofline for each is bytes moved / 8 TB/s (see DESIGN.md for the per-kernel byte counts).
+#include "dx_common.h"
+#include <algorithm>
+
+namespace {
+
+constexpr float LN_EPS = 1e-5f;
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm family.  z = drop_pre(a) + res  (written back over `a`), y = mask(film(drop_post(LN(z))))
+// ------------------------------------------------------------------------------------------------
+struct LnArgs {
+  float* a;            // [rows][C] in: GEMM output; out: z (kept for backward)
+  const float* res;    // [rows][C] or null
+  const float* w; const float* bias;   // LN affine [C]
+  const float* film; int ld_film;      // [B][>=2C] gamma | beta, or null
+  const int* lens;     // [B] or null (no mask)
+  float* y;            // [rows][C]
+  float* mean; float* rstd;            // [rows]
+  int B, N;
+  uint64_t seed_pre; uint32_t thresh_pre; float inv_keep_pre;     // dropout on `a` (thresh 0 = off)
+  uint64_t seed_post; uint32_t thresh_post; float inv_keep_post;  // dropout on LN output
+};
+
+template <int C> struct RowVec {
+  static constexpr int V = (C >= 256) ? 4 : 2;          // floats per access
+  static constexpr int K = C / (64 * V);                // accesses per lane
+  static_assert(C % (64 * V) == 0, "C must be a multiple of 128");
+};
+
+template <int C>
+__device__ __forceinline__ void row_load(const float* p, int lane, float v[RowVec<C>::K * RowVec<C>::V]) {
+  constexpr int V = RowVec<C>::V, K = RowVec<C>::K;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int c = (k * 64 + lane) * V;
+    if constexpr (V == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(p + c);
+      v[k * 4 + 0] = t.x; v[k * 4 + 1] = t.y; v[k * 4 + 2] = t.z; v[k * 4 + 3] = t.w;
+    } else {
+      const float2 t = *reinterpret_cast<const float2*>(p + c);
+      v[k * 2 + 0] = t.x; v[k * 2 + 1] = t.y;
+    }
+  }
+}
+template <int C>
+__device__ __forceinline__ void row_store(float* p, int lane, const float v[RowVec<C>::K * RowVec<C>::V]) {
+  constexpr int V = RowVec<C>::V, K = RowVec<C>::K;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int c = (k * 64 + lane) * V;
+    if constexpr (V == 4) *reinterpret_cast<float4*>(p + c) = make_float4(v[k * 4], v[k * 4 + 1], v[k * 4 + 2], v[k * 4 + 3]);
+    else *reinterpret_cast<float2*>(p + c) = make_float2(v[k * 2], v[k * 2 + 1]);
+  }
+}
+template <int C> __device__ __forceinline__ int row_col(int lane, int idx) {
+  constexpr int V = RowVec<C>::V;
+  return ((idx / V) * 64 + lane) * V + (idx % V);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
+  constexpr int E = RowVec<C>::K * RowVec<C>::V;
+  const int lane = threadIdx.x & 63;
+  const long rows = (long)a.B * a.N;
+  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+    const int b = (int)(row / a.N), n = (int)(row - (long)b * a.N);
+    const bool valid = !a.lens || n < a.lens[b];
+    float z[E];
+    row_load<C>(a.a + row * C, lane, z);
+    if (a.thresh_pre) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) z[e] *= dx_dropout_scale(a.seed_pre, (uint64_t)row * C + row_col<C>(lane, e), a.thresh_pre, a.inv_keep_pre);
+    }
+    if (a.res) {
+      float rv[E];
+      row_load<C>(a.res + row * C, lane, rv);
+#pragma unroll
+      for (int e = 0; e < E; ++e) z[e] += rv[e];
+    }
+    if (a.thresh_pre || a.res) row_store<C>(a.a + row * C, lane, z);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) s += z[e];
+    const float mu = dx_wave_sum(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { const float d = z[e] - mu; q += d * d; }
+    const float rs = 1.0f / sqrtf(dx_wave_sum(q) * (1.0f / C) + LN_EPS);
+    if (lane == 0) { a.mean[row] = mu; a.rstd[row] = rs; }
+    float y[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int c = row_col<C>(lane, e);
+      float t = (z[e] - mu) * rs * a.w[c] + a.bias[c];
+      if (a.thresh_post) t *= dx_dropout_scale(a.seed_post, (uint64_t)row * C + c, a.thresh_post, a.inv_keep_post);
+      if (a.film) t = a.film[(size_t)b * a.ld_film + c] * t + a.film[(size_t)b * a.ld_film + C + c];
+      y[e] = valid ? t : 0.f;
+    }
+    row_store<C>(a.y + row * C, lane, y);
+  }
+}
+
+struct LnBwdArgs {
+  const float* dy;     // [rows][C]
+  const float* z; const float* mean; const float* rstd;
+  const float* w; const float* bias;
+  const float* film; int ld_film;
+  const int* lens;
+  float* dz;           // [rows][C] gradient w.r.t. z (== residual branch gradient)
+  float* da;           // [rows][C] gradient w.r.t. the pre-dropout GEMM output, or null (then dz serves)
+  float* dw; float* dbias;             // [C] accumulated (atomics)
+  float* dfilm; int ld_dfilm;          // [B][>=2C] accumulated, or null
+  int B, N, rows_per_block;
+  int relu_mask;       // multiply dz by (z > 0): ReLU sits right before the LayerNorm (prenet)
+  uint64_t seed_pre; uint32_t thresh_pre; float inv_keep_pre;
+  uint64_t seed_post; uint32_t thresh_post; float inv_keep_post;
+};
+
+// grid: (blocks per batch row, B); each wave walks rows of ONE batch row so FiLM gradients reduce per b.
+template <int C>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
+  constexpr int E = RowVec<C>::K * RowVec<C>::V;
+  __shared__ float red[4][C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int n_begin = blockIdx.x * a.rows_per_block;
+  const int n_end = min(a.N, n_begin + a.rows_per_block);
+  const int len_b = a.lens ? a.lens[b] : a.N;
+  float gw[E], gb[E], gfg[E], gfb[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) gw[e] = gb[e] = gfg[e] = gfb[e] = 0.f;
+  float wv[E], bv[E], fg[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int c = row_col<C>(lane, e);
+    wv[e] = a.w[c]; bv[e] = a.bias[c];
+    fg[e] = a.film ? a.film[(size_t)b * a.ld_film + c] : 1.f;
+  }
+  for (int n = n_begin + wave; n < n_end; n += 4) {
+    const long row = (long)b * a.N + n;
+    float dzv[E];
+    if (n >= len_b) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) dzv[e] = 0.f;
+      row_store<C>(a.dz + row * C, lane, dzv);
+      if (a.da) row_store<C>(a.da + row * C, lane, dzv);
+      continue;
+    }
+    float dy[E], z[E];
+    row_load<C>(a.dy + row * C, lane, dy);
+    row_load<C>(a.z + row * C, lane, z);
+    const float mu = a.mean[row], rs = a.rstd[row];
+    float s1 = 0.f, s2 = 0.f, g[E], xh[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int c = row_col<C>(lane, e);
+      xh[e] = (z[e] - mu) * rs;
+      float ln = xh[e] * wv[e] + bv[e];                 // LayerNorm output (before post-dropout / FiLM)
+      float d = dy[e];
+      float post = 1.f;
+      if (a.thresh_post) post = dx_dropout_scale(a.seed_post, (uint64_t)row * C + c, a.thresh_post, a.inv_keep_post);
+      if (a.film) { gfg[e] += d * ln * post; gfb[e] += d; d *= fg[e]; }
+      d *= post;                                        // gradient w.r.t. LN output
+      gw[e] += d * xh[e]; gb[e] += d;
+      g[e] = d * wv[e];
+      s1 += g[e]; s2 += g[e] * xh[e];
+    }
+    s1 = dx_wave_sum(s1) * (1.0f / C);
+    s2 = dx_wave_sum(s2) * (1.0f / C);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      dzv[e] = rs * (g[e] - s1 - xh[e] * s2);
+      if (a.relu_mask && !(z[e] > 0.f)) dzv[e] = 0.f;
+    }
+    row_store<C>(a.dz + row * C, lane, dzv);
+    if (a.da) {
+      if (a.thresh_pre) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) dzv[e] *= dx_dropout_scale(a.seed_pre, (uint64_t)row * C + row_col<C>(lane, e), a.thresh_pre, a.inv_keep_pre);
+      }
+      row_store<C>(a.da + row * C, lane, dzv);
+    }
+  }
+  // block reduction of the per-channel sums, then one atomic per channel per block
+  auto reduce_and_add = [&](float* vals, float* dst) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) red[wave][row_col<C>(lane, e)] = vals[e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const float s = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+      if (s != 0.f) atomicAdd(&dst[c], s);
+    }
+  };
+  reduce_and_add(gw, a.dw);
+  reduce_and_add(gb, a.dbias);
+  if (a.dfilm) {
+    reduce_and_add(gfg, a.dfilm + (size_t)b * a.ld_dfilm);
+    reduce_and_add(gfb, a.dfilm + (size_t)b * a.ld_dfilm + C);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// embedding / positional encoding / masks
+// ------------------------------------------------------------------------------------------------
+// out[b,n,:] = n < len ? (emb ? emb[sym[b,n]] : x[b,n,:]) + pe[n] : 0          (D = 128)
+__global__ __launch_bounds__(256) void add_pos_kernel(const float* __restrict__ x, const long* __restrict__ sym, const float* __restrict__ emb,
+                                                      const float* __restrict__ pe, const int* __restrict__ lens,
+                                                      float* __restrict__ out, int B, int N, int D) {
+  const int lane = threadIdx.x & 63;
+  const long rows = (long)B * N;
+  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+    const int b = (int)(row / N), n = (int)(row - (long)b * N);
+    const bool valid = n < lens[b];
+    for (int c = lane * 2; c < D; c += 128) {
+      float2 v = make_float2(0.f, 0.f);
+      if (valid) {
+        const float2 s = emb ? *reinterpret_cast<const float2*>(emb + (size_t)sym[row] * D + c)
+                             : *reinterpret_cast<const float2*>(x + row * D + c);
+        const float2 p = *reinterpret_cast<const float2*>(pe + (size_t)n * D + c);
+        v = make_float2(s.x + p.x, s.y + p.y);
+      }
+      *reinterpret_cast<float2*>(out + row * D + c) = v;
+    }
+  }
+}
+
+// out[b,n,:] = n < len ? in[b,n,:] : 0   (masked_fill backward, pooled-gradient masks)
+__global__ __launch_bounds__(256) void mask_rows_kernel(const float* __restrict__ in, const int* __restrict__ lens, float* __restrict__ out,
+                                                        int B, int N, int C) {
+  const long total4 = (long)B * N * C / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const long row = (i * 4) / C;
+    const int b = (int)(row / N), n = (int)(row - (long)b * N);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < lens[b]) v = reinterpret_cast<const float4*>(in)[i];
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+}
+
+// demb[sym[b,n]] += dout[b,n,:] for valid rows
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restrict__ dout, const long* __restrict__ sym, const int* __restrict__ lens,
+                                                            float* __restrict__ demb, int B, int N, int D) {
+  const int lane = threadIdx.x & 63;
+  const long rows = (long)B * N;
+  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+    const int b = (int)(row / N), n = (int)(row - (long)b * N);
+    if (n >= lens[b]) continue;
+    const long s = sym[row];
+    for (int c = lane; c < D; c += 64) atomicAdd(&demb[(size_t)s * D + c], dout[row * D + c]);
+  }
+}
+
+// accent-encoder input: out = mask(prenet + conv1->D(energy) + conv1->D(pitch) + pe)      D == 128
+__global__ __launch_bounds__(256) void accent_sum_kernel(const float* __restrict__ prenet, const float* __restrict__ energy, const float* __restrict__ pitch,
+                                                         const float* __restrict__ we, const float* __restrict__ be,
+                                                         const float* __restrict__ wp, const float* __restrict__ bp,
+                                                         const float* __restrict__ pe, const int* __restrict__ lens,
+                                                         float* __restrict__ out, int B, int N) {
+  constexpr int D = 128;
+  const int lane = threadIdx.x & 63;
+  const int c = lane * 2;
+  float wE[2][3], wP[2][3], bE[2], bP[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { wE[k][t] = we[(c + k) * 3 + t]; wP[k][t] = wp[(c + k) * 3 + t]; }
+    bE[k] = be[c + k]; bP[k] = bp[c + k];
+  }
+  const long rows = (long)B * N;
+  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+    const int b = (int)(row / N), n = (int)(row - (long)b * N);
+    float2 v = make_float2(0.f, 0.f);
+    if (n < lens[b]) {
+      const float* eb = energy + (size_t)b * N;
+      const float* pb = pitch + (size_t)b * N;
+      const float e0 = n > 0 ? eb[n - 1] : 0.f, e1 = eb[n], e2 = n + 1 < N ? eb[n + 1] : 0.f;
+      const float p0 = n > 0 ? pb[n - 1] : 0.f, p1 = pb[n], p2 = n + 1 < N ? pb[n + 1] : 0.f;
+      const float2 pr = *reinterpret_cast<const float2*>(prenet + row * D + c);
+      const float2 ps = *reinterpret_cast<const float2*>(pe + (size_t)n * D + c);
+      float ev[2], pv[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        ev[k] = bE[k] + (wE[k][0] * e0 + wE[k][1] * e1 + wE[k][2] * e2);
+        pv[k] = bP[k] + (wP[k][0] * p0 + wP[k][1] * p1 + wP[k][2] * p2);
+      }
+      v = make_float2(((pr.x + ev[0]) + pv[0]) + ps.x, ((pr.y + ev[1]) + pv[1]) + ps.y);  // reference order, model.py:705
+    }
+    *reinterpret_cast<float2*>(out + row * D + c) = v;
+  }
+}
+
+// gradients of the two Conv1d(1->D) embeddings from dout (already masked): dW[c][t] += sum dout[b,n,c] * s[b,n+t-1]
+// thread = channel (128 per half block), two halves interleave rows.
+__global__ __launch_bounds__(256) void scalar_conv_wgrad_kernel(const float* __restrict__ dout, int ldd, const float* __restrict__ rowscale,
+                                                                const float* __restrict__ s0, const float* __restrict__ s1,
+                                                                const int* __restrict__ lens,
+                                                                float* __restrict__ dw0, float* __restrict__ db0,
+                                                                float* __restrict__ dw1, float* __restrict__ db1,
+                                                                int B, int N, int rows_per_block) {
+  constexpr int D = 128;
+  const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
+  const int b = blockIdx.y;
+  const int n_begin = blockIdx.x * rows_per_block;
+  const int n_end = min(min(N, n_begin + rows_per_block), lens[b]);
+  float a0[3] = {0.f, 0.f, 0.f}, a1[3] = {0.f, 0.f, 0.f}, ab = 0.f;
+  const float* x0 = s0 + (size_t)b * N;
+  const float* x1 = s1 ? s1 + (size_t)b * N : nullptr;
+  for (int n = n_begin + half; n < n_end; n += 2) {
+    float g = dout[((size_t)b * N + n) * ldd + c];
+    if (rowscale) g *= rowscale[(size_t)b * N + n];
+    ab += g;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int m = n + t - 1;
+      const bool in = m >= 0 && m < N;
+      a0[t] += g * (in ? x0[m] : 0.f);
+      if (x1) a1[t] += g * (in ? x1[m] : 0.f);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    atomicAdd(&dw0[c * 3 + t], a0[t]);
+    if (x1) atomicAdd(&dw1[c * 3 + t], a1[t]);
+  }
+  atomicAdd(&db0[c], ab);
+  if (x1) atomicAdd(&db1[c], ab);
+}
+
+// pooled[b,c] += sum_{n in chunk} x[b,n,c] / len_b
+__global__ __launch_bounds__(128) void mean_pool_kernel(const float* __restrict__ x, const int* __restrict__ lens, float* __restrict__ out,
+                                                        int B, int N, int C, int rows_per_block) {
+  const int b = blockIdx.y, c = threadIdx.x;
+  const int n_begin = blockIdx.x * rows_per_block, n_end = min(N, n_begin + rows_per_block);
+  for (int cc = c; cc < C; cc += 128) {
+    float s = 0.f;
+    for (int n = n_begin; n < n_end; ++n) s += x[((size_t)b * N + n) * C + cc];
+    atomicAdd(&out[(size_t)b * C + cc], s / (float)lens[b]);
+  }
+}
+
+// dx[b,n,c] = n < len ? dout[b,c] / len_b : 0
+__global__ __launch_bounds__(256) void mean_pool_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ lens, float* __restrict__ dx,
+                                                            int B, int N, int C) {
+  const long total = (long)B * N * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long row = i / C;
+    const int b = (int)(row / N), n = (int)(row - (long)b * N);
+    dx[i] = n < lens[b] ? dout[(size_t)b * C + c] / (float)lens[b] : 0.f;
+  }
+}
+
+// batched transpose in[b][R][Cc] -> out[b][Cc][R]
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* ib = in + (size_t)b * R * Cc;
+  float* ob = out + (size_t)b * R * Cc;
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    tile[k][tx] = (r < R && c < Cc) ? ib[(size_t)r * Cc + c] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, r = r0 + tx;
+    if (c < Cc && r < R) ob[(size_t)c * R + r] = tile[tx][k];
+  }
+}
+
+// y = x / max(||x||_2, 1e-12) per row (F.normalize)
+__global__ __launch_bounds__(64) void l2_normalize_kernel(const float* __restrict__ x, float* __restrict__ y, int C) {
+  const int row = blockIdx.x, lane = threadIdx.x;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) { const float v = x[(size_t)row * C + c]; s += v * v; }
+  const float nrm = fmaxf(sqrtf(dx_wave_sum(s)), 1e-12f);
+  for (int c = lane; c < C; c += 64) y[(size_t)row * C + c] = x[(size_t)row * C + c] / nrm;
+}
+
+// mean cross entropy over B rows of S logits; dlogits = (softmax - onehot) / B.  One block.
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits, const long* __restrict__ target,
+                                                            float* __restrict__ loss, float* __restrict__ dlogits, int B, int S) {
+  __shared__ float part[256];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float* l = logits + (size_t)b * S;
+    float m = -INFINITY;
+    for (int s = 0; s < S; ++s) m = fmaxf(m, l[s]);
+    float z = 0.f;
+    for (int s = 0; s < S; ++s) z += expf(l[s] - m);
+    const float lse = m + logf(z);
+    acc += lse - l[target[b]];
+    for (int s = 0; s < S; ++s) dlogits[(size_t)b * S + s] = (expf(l[s] - lse) - (s == target[b] ? 1.f : 0.f)) / (float)B;
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = part[0] / (float)B;
+}
+
+inline int row_grid(long rows) { return (int)std::min<long>((rows + 3) / 4, 8192); }
+
+}  // namespace
+
+extern "C" {
+
+int dx_ln_fwd(float* a, const float* res, const float* w, const float* bias, const float* film, int ld_film,
+              const int* lens, float* y, float* mean, float* rstd, int B, int N, int C,
+              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, void* stream) {
+  DX_REQUIRE(a && w && bias && y && mean && rstd, "dx_ln_fwd: null pointer");
+  DX_REQUIRE(C == 128 || C == 1024, "dx_ln_fwd: C must be 128 or 1024 (got %d)", C);
+  DX_REQUIRE(B > 0 && N > 0, "dx_ln_fwd: bad dims");
+  DX_REQUIRE(p_pre >= 0.f && p_pre < 1.f && p_post >= 0.f && p_post < 1.f, "dx_ln_fwd: dropout p out of range");
+  DX_REQUIRE(!film || ld_film >= 2 * C, "dx_ln_fwd: ld_film too small");
+  LnArgs k{a, res, w, bias, film, ld_film, lens, y, mean, rstd, B, N,
+           seed_pre, (uint32_t)lrintf(p_pre * 65536.f), 1.f / (1.f - p_pre),
+           seed_post, (uint32_t)lrintf(p_post * 65536.f), 1.f / (1.f - p_post)};
+  hipStream_t s = (hipStream_t)stream;
+  dx_prof_begin(DX_PROF_ROWS, s);
+  const int grid = row_grid((long)B * N);
+  if (C == 128) hipLaunchKernelGGL(ln_fwd_kernel<128>, dim3(grid), dim3(256), 0, s, k);
+  else hipLaunchKernelGGL(ln_fwd_kernel<1024>, dim3(grid), dim3(256), 0, s, k);
+  dx_prof_end(DX_PROF_ROWS, s);
+  DX_LAUNCH_CHECK("dx_ln_fwd");
+  return DX_OK;
+}
+
+int dx_ln_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* w, const float* bias,
+              const float* film, int ld_film, const int* lens, float* dz, float* da, float* dw, float* dbias,
+              float* dfilm, int ld_dfilm, int B, int N, int C, int relu_mask,
+              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, void* stream) {
+  DX_REQUIRE(dy && z && mean && rstd && w && bias && dz && dw && dbias, "dx_ln_bwd: null pointer");
+  DX_REQUIRE(C == 128 || C == 1024, "dx_ln_bwd: C must be 128 or 1024 (got %d)", C);
+  DX_REQUIRE((film == nullptr) == (dfilm == nullptr), "dx_ln_bwd: film and dfilm must come together");
+  const int rpb = 64;
+  LnBwdArgs k{dy, z, mean, rstd, w, bias, film, ld_film, lens, dz, da, dw, dbias, dfilm, ld_dfilm, B, N, rpb, relu_mask,
+              seed_pre, (uint32_t)lrintf(p_pre * 65536.f), 1.f / (1.f - p_pre),
+              seed_post, (uint32_t)lrintf(p_post * 65536.f), 1.f / (1.f - p_post)};
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(dx_cdiv(N, rpb), B);
+  dx_prof_begin(DX_PROF_ROWS, s);
+  if (C == 128) hipLaunchKernelGGL(ln_bwd_kernel<128>, grid, dim3(256), 0, s, k);
+  else hipLaunchKernelGGL(ln_bwd_kernel<1024>, grid, dim3(256), 0, s, k);
+  dx_prof_end(DX_PROF_ROWS, s);
+  DX_LAUNCH_CHECK("dx_ln_bwd");
+  return DX_OK;
+}
+
+// out = mask(emb[sym] + pe)  (emb != null)   or   out = mask(x + pe)  (emb == null)
+int dx_add_pos(const float* x, const long* sym, const float* emb, const float* pe, const int* lens, float* out,
+               int B, int N, int D, int pe_rows, void* stream) {
+  DX_REQUIRE(pe && lens && out && (emb ? (sym != nullptr) : (x != nullptr)), "dx_add_pos: null pointer");
+  DX_REQUIRE(B > 0 && N > 0 && D > 0 && (D % 2) == 0, "dx_add_pos: bad dims");
+  DX_REQUIRE(N <= pe_rows, "dx_add_pos: sequence length %d exceeds the positional table (%d rows)", N, pe_rows);
+  hipLaunchKernelGGL(add_pos_kernel, dim3(row_grid((long)B * N)), dim3(256), 0, (hipStream_t)stream, x, sym, emb, pe, lens, out, B, N, D);
+  DX_LAUNCH_CHECK("dx_add_pos");
+  return DX_OK;
+}
+
+int dx_mask_rows(const float* in, const int* lens, float* out, int B, int N, int C, void* stream) {
+  DX_REQUIRE(in && lens && out && B > 0 && N > 0 && C > 0 && (C % 4) == 0, "dx_mask_rows: bad arguments");
+  const long total4 = (long)B * N * C / 4;
+  hipLaunchKernelGGL(mask_rows_kernel, dim3((int)std::min<long>((total4 + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream, in, lens, out, B, N, C);
+  DX_LAUNCH_CHECK("dx_mask_rows");
+  return DX_OK;
+}
+
+int dx_embedding_bwd(const float* dout, const long* sym, const int* lens, float* demb, int B, int N, int D, void* stream) {
+  DX_REQUIRE(dout && sym && lens && demb && B > 0 && N > 0 && D > 0, "dx_embedding_bwd: bad arguments");
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(row_grid((long)B * N)), dim3(256), 0, (hipStream_t)stream, dout, sym, lens, demb, B, N, D);
+  DX_LAUNCH_CHECK("dx_embedding_bwd");
+  return DX_OK;
+}
+
+int dx_accent_sum(const float* prenet, const float* energy, const float* pitch, const float* we, const float* be,
+                  const float* wp, const float* bp, const float* pe, const int* lens, float* out,
+                  int B, int N, int D, int pe_rows, void* stream) {
+  DX_REQUIRE(prenet && energy && pitch && we && be && wp && bp && pe && lens && out, "dx_accent_sum: null pointer");
+  DX_REQUIRE(D == 128, "dx_accent_sum: hidden dim must be 128 (got %d)", D);
+  DX_REQUIRE(N <= pe_rows, "dx_accent_sum: sequence length %d exceeds the positional table (%d rows)", N, pe_rows);
+  hipLaunchKernelGGL(accent_sum_kernel, dim3(row_grid((long)B * N)), dim3(256), 0, (hipStream_t)stream,
+                     prenet, energy, pitch, we, be, wp, bp, pe, lens, out, B, N);
+  DX_LAUNCH_CHECK("dx_accent_sum");
+  return DX_OK;
+}
+
+// dW0[c][t] += sum_{b, n < len_b} rowscale[b,n] * dout[b,n,c] * s0[b,n+t-1]; db0[c] += ...; same for (s1, dW1, db1) if s1.
+int dx_scalar_conv_wgrad(const float* dout, int ldd, const float* rowscale, const float* s0, const float* s1, const int* lens,
+                         float* dw0, float* db0, float* dw1, float* db1, int B, int N, int D, void* stream) {
+  DX_REQUIRE(dout && s0 && lens && dw0 && db0, "dx_scalar_conv_wgrad: null pointer");
+  DX_REQUIRE(D == 128 && ldd >= 0, "dx_scalar_conv_wgrad: hidden dim must be 128");  // ldd == 0: one row broadcast
+  DX_REQUIRE(!s1 || (dw1 && db1), "dx_scalar_conv_wgrad: second stream needs its gradient buffers");
+  const int rpb = 64;
+  hipLaunchKernelGGL(scalar_conv_wgrad_kernel, dim3(dx_cdiv(N, rpb), B), dim3(256), 0, (hipStream_t)stream,
+                     dout, ldd, rowscale, s0, s1, lens, dw0, db0, dw1, db1, B, N, rpb);
+  DX_LAUNCH_CHECK("dx_scalar_conv_wgrad");
+  return DX_OK;
+}
+
+// out (caller-zeroed) [B][C]
+int dx_mean_pool(const float* x, const int* lens, float* out, int B, int N, int C, void* stream) {
+  DX_REQUIRE(x && lens && out && B > 0 && N > 0 && C > 0, "dx_mean_pool: bad arguments");
+  const int rpb = 32;
+  hipLaunchKernelGGL(mean_pool_kernel, dim3(dx_cdiv(N, rpb), B), dim3(128), 0, (hipStream_t)stream, x, lens, out, B, N, C, rpb);
+  DX_LAUNCH_CHECK("dx_mean_pool");
+  return DX_OK;
+}
+
+int dx_mean_pool_bwd(const float* dout, const int* lens, float* dx, int B, int N, int C, void* stream) {
+  DX_REQUIRE(dout && lens && dx && B > 0 && N > 0 && C > 0, "dx_mean_pool_bwd: bad arguments");
+  const long total = (long)B * N * C;
+  hipLaunchKernelGGL(mean_pool_bwd_kernel, dim3((int)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream, dout, lens, dx, B, N, C);
+  DX_LAUNCH_CHECK("dx_mean_pool_bwd");
+  return DX_OK;
+}
+
+int dx_transpose(const float* in, float* out, int B, int R, int Cc, void* stream) {
+  DX_REQUIRE(in && out && B > 0 && R > 0 && Cc > 0, "dx_transpose: bad arguments");
+  hipLaunchKernelGGL(transpose_kernel, dim3(dx_cdiv(Cc, 32), dx_cdiv(R, 32), B), dim3(256), 0, (hipStream_t)stream, in, out, R, Cc);
+  DX_LAUNCH_CHECK("dx_transpose");
+  return DX_OK;
+}
+
+int dx_l2_normalize(const float* x, float* y, int rows, int C, void* stream) {
+  DX_REQUIRE(x && y && rows > 0 && C > 0, "dx_l2_normalize: bad arguments");
+  hipLaunchKernelGGL(l2_normalize_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, x, y, C);
+  DX_LAUNCH_CHECK("dx_l2_normalize");
+  return DX_OK;
+}
+
+int dx_cross_entropy(const float* logits, const long* target, float* loss, float* dlogits, int B, int S, void* stream) {
+  DX_REQUIRE(logits && target && loss && dlogits && B > 0 && S > 0, "dx_cross_entropy: bad arguments");
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, loss, dlogits, B, S);
+  DX_LAUNCH_CHECK("dx_cross_entropy");
+  return DX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,390 @@
+// Gaussian upsampling (reference: src/daft_exprt/model.py:417-510) without the B*L*D*T broadcast.
+//
+//   prep     xs[b,l,:] = enc + conv1->D(energy) + conv1->D(pitch);  z = (xs + conv1->D(dur)) . w_r + b_r
+//            sigma = max(l < len ? softplus(z) : 1, 1e-3);  mu = dur_int/2 + exclusive_cumsum(dur_int)   (int64 -> exact)
+//   weights  p[l,t] = exp(-((t+.5-mu)^2)/(2 sigma^2) - log sigma - log sqrt(2 pi)), 0 for l >= len
+//            w = p / (sum_l p + 1e-20)  -> weights (B, L, T) (returned tensor), x_up[b,t,:] = sum_l w[l,t] xs[b,l,:]
+//   backward dxs, dsigma via w (d log p), then the symbol-level parameter gradients.
+//
+// HBM traffic (fp32): reads B*L*D + 4*B*L, writes B*T*D + B*L*T  (35 MB at B=48, L=120, T=840; the reference
+// materialises 2 GB).  One workgroup owns TT frames of one utterance and keeps the [L][TT] weight tile in LDS.
+#include "dx_common.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int D = 128;
+constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
+
+__device__ __forceinline__ float softplus_ref(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+// one block per utterance: exclusive cumsum of integer durations (int64), means, total frames
+__global__ __launch_bounds__(64) void dur_scan_kernel(const long* __restrict__ dur_int, float* __restrict__ mu, long* __restrict__ totals, int L) {
+  const int b = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  long run = 0;
+  for (int l = 0; l < L; ++l) {
+    const long d = dur_int[(size_t)b * L + l];
+    mu[(size_t)b * L + l] = (float)d / 2.f + (float)run;   // dur_int.float()/2 + cumsum[:-1] (model.py:485-487)
+    run += d;
+  }
+  totals[b] = run;
+}
+
+struct PrepArgs {
+  const float* enc; const float* dur; const float* energy; const float* pitch;
+  const float* wd; const float* bd; const float* we; const float* be; const float* wp; const float* bp;
+  const float* wr; const float* br;
+  const int* lens;
+  float* xs; float* z; float* sigma;
+  int B, L;
+};
+
+// wave per symbol row; lane owns channels 2*lane, 2*lane+1
+__global__ __launch_bounds__(256) void upsample_prep_kernel(const PrepArgs a) {
+  const int lane = threadIdx.x & 63, c = lane * 2;
+  float wD[2][3], wE[2][3], wP[2][3], bD[2], bE[2], bP[2], wR[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { wD[k][t] = a.wd[(c + k) * 3 + t]; wE[k][t] = a.we[(c + k) * 3 + t]; wP[k][t] = a.wp[(c + k) * 3 + t]; }
+    bD[k] = a.bd[c + k]; bE[k] = a.be[c + k]; bP[k] = a.bp[c + k]; wR[k] = a.wr[c + k];
+  }
+  const float br = a.br[0];
+  const long rows = (long)a.B * a.L;
+  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+    const int b = (int)(row / a.L), l = (int)(row - (long)b * a.L);
+    const float* db = a.dur + (size_t)b * a.L; const float* eb = a.energy + (size_t)b * a.L; const float* pb = a.pitch + (size_t)b * a.L;
+    const bool lo = l > 0, hi = l + 1 < a.L;
+    const float d0 = lo ? db[l - 1] : 0.f, d1 = db[l], d2 = hi ? db[l + 1] : 0.f;
+    const float e0 = lo ? eb[l - 1] : 0.f, e1 = eb[l], e2 = hi ? eb[l + 1] : 0.f;
+    const float p0 = lo ? pb[l - 1] : 0.f, p1 = pb[l], p2 = hi ? pb[l + 1] : 0.f;
+    const float2 x = *reinterpret_cast<const float2*>(a.enc + row * D + c);
+    float xv[2] = {x.x, x.y}, dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float ev = bE[k] + (wE[k][0] * e0 + wE[k][1] * e1 + wE[k][2] * e2);
+      const float pv = bP[k] + (wP[k][0] * p0 + wP[k][1] * p1 + wP[k][2] * p2);
+      const float dv = bD[k] + (wD[k][0] * d0 + wD[k][1] * d1 + wD[k][2] * d2);
+      xv[k] = (xv[k] + ev) + pv;                       // model.py:470
+      dot += (xv[k] + dv) * wR[k];                     // model.py:475-476
+    }
+    *reinterpret_cast<float2*>(a.xs + row * D + c) = make_float2(xv[0], xv[1]);
+    dot = dx_wave_sum(dot) + br;
+    if (lane == 0) {
+      a.z[row] = dot;
+      const float rng = l < a.lens[b] ? softplus_ref(dot) : 1.f;
+      a.sigma[row] = fmaxf(rng, 1e-3f);
+    }
+  }
+}
+
+struct UpArgs {
+  const float* xs; const float* mu; const float* sigma; const int* lens;
+  float* weights;      // [B][L][T]
+  float* xup;          // [B][T][D]
+  int B, L, T;
+};
+
+// grid (ceil(T/TT), B), 256 threads.  LDS: wt[L][TT] + colsum[4][TT]
+template <int TT>
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const UpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* wt = smem;                       // [L][TT]
+  float* part = smem + (size_t)a.L * TT;  // [4][TT]
+  const int b = blockIdx.y, t0 = blockIdx.x * TT;
+  const int tid = threadIdx.x;
+  const int len = a.lens[b];
+  const float* mu = a.mu + (size_t)b * a.L;
+  const float* sg = a.sigma + (size_t)b * a.L;
+  // pass 1: probabilities into LDS, column sums
+  {
+    constexpr int LG = 256 / TT;          // symbol groups walking l in parallel
+    const int tt = tid % TT, lg = tid / TT;
+    const float tv = (float)(t0 + tt) + 0.5f;
+    float s = 0.f;
+    for (int l = lg; l < a.L; l += LG) {
+      float p = 0.f;
+      if (l < len) {
+        const float sd = sg[l], d = tv - mu[l];
+        p = expf(-(d * d) / (2.f * (sd * sd)) - logf(sd) - LOG_SQRT_2PI);
+      }
+      wt[(size_t)l * TT + tt] = p;
+      s += p;
+    }
+    // reduce the LG partial sums per frame through LDS
+    __syncthreads();
+    float* red = part;                    // reuse as [LG][TT] (LG <= 16 -> need LG*TT floats)
+    red[lg * TT + tt] = s;
+    __syncthreads();
+    if (lg == 0) {
+      float tot = 0.f;
+      for (int k = 0; k < LG; ++k) tot += red[k * TT + tt];
+      red[tt] = tot + 1e-20f;
+    }
+    __syncthreads();
+    const float den = red[tt];
+    for (int l = lg; l < a.L; l += LG) {
+      const float w = wt[(size_t)l * TT + tt] / den;   // model.py:505
+      wt[(size_t)l * TT + tt] = w;
+      if (t0 + tt < a.T) a.weights[((size_t)b * a.L + l) * a.T + t0 + tt] = w;
+    }
+    __syncthreads();
+  }
+  // pass 2: x_up[t][c] = sum_l w[l][t] * xs[l][c];  thread = channel c (128) x half of the frames
+  {
+    constexpr int TH = TT / 2;
+    const int c = tid & 127, th = tid >> 7;
+    float acc[TH];
+#pragma unroll
+    for (int k = 0; k < TH; ++k) acc[k] = 0.f;
+    const float* xb = a.xs + (size_t)b * a.L * D;
+    for (int l = 0; l < len; ++l) {
+      const float xv = xb[(size_t)l * D + c];
+      const float* wrow = wt + (size_t)l * TT + th * TH;
+#pragma unroll
+      for (int k = 0; k < TH; k += 4) {
+        const float4 w4 = *reinterpret_cast<const float4*>(wrow + k);
+        acc[k] += w4.x * xv; acc[k + 1] += w4.y * xv; acc[k + 2] += w4.z * xv; acc[k + 3] += w4.w * xv;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < TH; ++k) {
+      const int t = t0 + th * TH + k;
+      if (t < a.T) a.xup[((size_t)b * a.T + t) * D + c] = acc[k];
+    }
+  }
+}
+
+struct UpBwdArgs {
+  const float* dxup;   // [B][T][D]
+  const float* xs; const float* mu; const float* sigma; const float* weights; const int* lens;
+  float* dxs;          // [B][L][D] accumulated (atomics, caller-zeroed)
+  float* dsigma;       // [B][L]    accumulated (atomics, caller-zeroed)
+  int B, L, T;
+};
+
+// grid (ceil(T/TT), B), 256 threads.  LDS: g[TT][D+4] (dx_up tile), dw[L][TT], w[L][TT], inner[TT]
+template <int TT>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const UpBwdArgs a) {
+  constexpr int GLD = D + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* gt = smem;                                   // [TT][GLD]
+  float* dwt = gt + TT * GLD;                         // [L][TT]
+  float* wt = dwt + (size_t)a.L * TT;                 // [L][TT]
+  float* inner = wt + (size_t)a.L * TT;               // [256] scratch
+  const int b = blockIdx.y, t0 = blockIdx.x * TT;
+  const int tid = threadIdx.x;
+  const int len = a.lens[b];
+  const float* xb = a.xs + (size_t)b * a.L * D;
+  // stage dx_up tile (zero beyond T) and the weight tile
+  for (int u = tid; u < TT * (D / 4); u += 256) {
+    const int tt = u / (D / 4), q = u % (D / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t0 + tt < a.T) v = *reinterpret_cast<const float4*>(a.dxup + ((size_t)b * a.T + t0 + tt) * D + q * 4);
+    *reinterpret_cast<float4*>(gt + tt * GLD + q * 4) = v;
+  }
+  for (int u = tid; u < a.L * TT; u += 256) {
+    const int l = u / TT, tt = u % TT;
+    wt[u] = (l < len && t0 + tt < a.T) ? a.weights[((size_t)b * a.L + l) * a.T + t0 + tt] : 0.f;
+  }
+  __syncthreads();
+  constexpr int LG = 256 / TT;
+  const int tt = tid % TT, lg = tid / TT;
+  // dw[l][t] = sum_c dxup[t][c] * xs[l][c]
+  float inn = 0.f;
+  for (int l = lg; l < len; l += LG) {
+    const float* xr = xb + (size_t)l * D;
+    const float* gr = gt + tt * GLD;
+    float s = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < D; c += 4) {
+      const float4 xv = *reinterpret_cast<const float4*>(xr + c);
+      const float4 gv = *reinterpret_cast<const float4*>(gr + c);
+      s += xv.x * gv.x + xv.y * gv.y + xv.z * gv.z + xv.w * gv.w;
+    }
+    dwt[(size_t)l * TT + tt] = s;
+    inn += s * wt[(size_t)l * TT + tt];
+  }
+  inner[lg * TT + tt] = inn;
+  __syncthreads();
+  if (lg == 0) {
+    float tot = 0.f;
+    for (int k = 0; k < LG; ++k) tot += inner[k * TT + tt];
+    inner[tt] = tot;
+  }
+  __syncthreads();
+  // d log p[l][t] = w (dw - inner[t]);  dsigma[l] += sum_t dlogp ((t+.5-mu)^2 / sigma^3 - 1/sigma)
+  // one wave per symbol l (4 at a time): lanes over frames
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    const float* mu = a.mu + (size_t)b * a.L;
+    const float* sg = a.sigma + (size_t)b * a.L;
+    for (int l = wave; l < len; l += 4) {
+      const float m = mu[l], sd = sg[l];
+      float s = 0.f;
+      for (int k = lane; k < TT; k += 64) {
+        const float w = wt[(size_t)l * TT + k];
+        const float dlp = w * (dwt[(size_t)l * TT + k] - inner[k]);
+        const float d = ((float)(t0 + k) + 0.5f) - m;
+        s += dlp * ((d * d) / (sd * sd * sd) - 1.f / sd);
+      }
+      s = dx_wave_sum(s);
+      if (lane == 0 && s != 0.f) atomicAdd(&a.dsigma[(size_t)b * a.L + l], s);
+    }
+  }
+  // dxs[l][c] += sum_t w[l][t] * dxup[t][c]; thread = channel x half of the symbols
+  {
+    const int c = tid & 127, lh = tid >> 7;
+    for (int l = lh; l < len; l += 2) {
+      const float* wrow = wt + (size_t)l * TT;
+      float s = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < TT; ++k) s += wrow[k] * gt[k * GLD + c];
+      if (s != 0.f) atomicAdd(&a.dxs[((size_t)b * a.L + l) * D + c], s);
+    }
+  }
+}
+
+struct SymBwdArgs {
+  const float* dxs_in;   // [B][L][D] gradient w.r.t. xs from the frame pass
+  const float* dsigma;   // [B][L]
+  const float* xs; const float* z; const float* dur; const int* lens;
+  const float* wd; const float* bd; const float* wr;
+  float* dxs_out;        // [B][L][D] total gradient w.r.t. xs (== d enc == d energy-proj == d pitch-proj outputs)
+  float* dz;             // [B][L]
+  float* dwr; float* dbr;  // [D], [1] accumulated
+  int B, L;
+};
+
+// wave per symbol row
+__global__ __launch_bounds__(256) void upsample_sym_bwd_kernel(const SymBwdArgs a) {
+  __shared__ float red[4][D];
+  __shared__ float redb[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane * 2;
+  float wD[2][3], bD[2], wR[2], gwr[2] = {0.f, 0.f}, gbr = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) wD[k][t] = a.wd[(c + k) * 3 + t];
+    bD[k] = a.bd[c + k]; wR[k] = a.wr[c + k];
+  }
+  const long rows = (long)a.B * a.L;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const int b = (int)(row / a.L), l = (int)(row - (long)b * a.L);
+    float dzv = 0.f;
+    if (l < a.lens[b]) {
+      const float zv = a.z[row];
+      const float rng = softplus_ref(zv);
+      // clamp(min=1e-3) passes the gradient where the input is >= min; softplus' = sigmoid (1 beyond the threshold 20)
+      if (rng >= 1e-3f) dzv = a.dsigma[row] * (zv > 20.f ? 1.f : 1.f / (1.f + expf(-zv)));
+    }
+    const float* db = a.dur + (size_t)b * a.L;
+    const float d0 = l > 0 ? db[l - 1] : 0.f, d1 = db[l], d2 = l + 1 < a.L ? db[l + 1] : 0.f;
+    const float2 g = *reinterpret_cast<const float2*>(a.dxs_in + row * D + c);
+    const float2 x = *reinterpret_cast<const float2*>(a.xs + row * D + c);
+    const float gv[2] = {g.x, g.y}, xv[2] = {x.x, x.y};
+    float o[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float dv = bD[k] + (wD[k][0] * d0 + wD[k][1] * d1 + wD[k][2] * d2);
+      gwr[k] += dzv * (xv[k] + dv);
+      o[k] = gv[k] + dzv * wR[k];
+    }
+    gbr += dzv;
+    *reinterpret_cast<float2*>(a.dxs_out + row * D + c) = make_float2(o[0], o[1]);
+    if (lane == 0) a.dz[row] = dzv;
+  }
+  red[wave][c] = gwr[0]; red[wave][c + 1] = gwr[1];
+  if (lane == 0) redb[wave] = gbr;
+  __syncthreads();
+  if (threadIdx.x < D) atomicAdd(&a.dwr[threadIdx.x], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+  if (threadIdx.x == 0) atomicAdd(&a.dbr[0], (redb[0] + redb[1]) + (redb[2] + redb[3]));
+}
+
+template <int TT> size_t fwd_smem(int L) { return ((size_t)L * TT + (size_t)(256 / TT) * TT) * sizeof(float); }
+template <int TT> size_t bwd_smem(int L) { return ((size_t)TT * (D + 4) + 2 * (size_t)L * TT + 256) * sizeof(float); }
+
+template <int TT>
+int launch_fwd(const UpArgs& a, hipStream_t s) {
+  const size_t smem = fwd_smem<TT>(a.L);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&upsample_fwd_kernel<TT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(upsample_fwd_kernel<TT>, dim3(dx_cdiv(a.T, TT), a.B), dim3(256), smem, s, a);
+  return DX_OK;
+}
+template <int TT>
+int launch_bwd(const UpBwdArgs& a, hipStream_t s) {
+  const size_t smem = bwd_smem<TT>(a.L);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&upsample_bwd_kernel<TT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(upsample_bwd_kernel<TT>, dim3(dx_cdiv(a.T, TT), a.B), dim3(256), smem, s, a);
+  return DX_OK;
+}
+
+constexpr size_t LDS_BUDGET = 150 * 1024;
+
+}  // namespace
+
+extern "C" {
+
+// mu[b,l] (fp32, exact for totals < 2^24) and totals[b] = sum_l dur_int[b,l] (int64)
+int dx_duration_scan(const long* dur_int, float* mu, long* totals, int B, int L, void* stream) {
+  DX_REQUIRE(dur_int && mu && totals && B > 0 && L > 0, "dx_duration_scan: bad arguments");
+  hipLaunchKernelGGL(dur_scan_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, dur_int, mu, totals, L);
+  DX_LAUNCH_CHECK("dx_duration_scan");
+  return DX_OK;
+}
+
+int dx_upsample_prep(const float* enc, const float* dur, const float* energy, const float* pitch,
+                     const float* wd, const float* bd, const float* we, const float* be, const float* wp, const float* bp,
+                     const float* wr, const float* br, const int* lens, float* xs, float* z, float* sigma,
+                     int B, int L, int Dm, void* stream) {
+  DX_REQUIRE(enc && dur && energy && pitch && wd && bd && we && be && wp && bp && wr && br && lens && xs && z && sigma, "dx_upsample_prep: null pointer");
+  DX_REQUIRE(Dm == D && B > 0 && L > 0, "dx_upsample_prep: hidden dim must be 128 (got %d)", Dm);
+  PrepArgs a{enc, dur, energy, pitch, wd, bd, we, be, wp, bp, wr, br, lens, xs, z, sigma, B, L};
+  const long rows = (long)B * L;
+  hipLaunchKernelGGL(upsample_prep_kernel, dim3((int)std::min<long>((rows + 3) / 4, 4096)), dim3(256), 0, (hipStream_t)stream, a);
+  DX_LAUNCH_CHECK("dx_upsample_prep");
+  return DX_OK;
+}
+
+int dx_upsample_fwd(const float* xs, const float* mu, const float* sigma, const int* lens, float* weights, float* xup,
+                    int B, int L, int T, int Dm, void* stream) {
+  DX_REQUIRE(xs && mu && sigma && lens && weights && xup, "dx_upsample_fwd: null pointer");
+  DX_REQUIRE(Dm == D && B > 0 && L > 0 && T > 0, "dx_upsample_fwd: bad dims (D must be 128)");
+  UpArgs a{xs, mu, sigma, lens, weights, xup, B, L, T};
+  hipStream_t s = (hipStream_t)stream;
+  dx_prof_begin(DX_PROF_UPSAMPLE, s);
+  if (fwd_smem<64>(L) <= LDS_BUDGET) launch_fwd<64>(a, s);
+  else if (fwd_smem<32>(L) <= LDS_BUDGET) launch_fwd<32>(a, s);
+  else { DX_REQUIRE(fwd_smem<16>(L) <= LDS_BUDGET, "dx_upsample_fwd: L=%d too long for the LDS weight tile", L); launch_fwd<16>(a, s); }
+  dx_prof_end(DX_PROF_UPSAMPLE, s);
+  DX_LAUNCH_CHECK("dx_upsample_fwd");
+  return DX_OK;
+}
+
+int dx_upsample_bwd(const float* dxup, const float* xs, const float* mu, const float* sigma, const float* weights, const int* lens,
+                    float* dxs, float* dsigma, int B, int L, int T, int Dm, void* stream) {
+  DX_REQUIRE(dxup && xs && mu && sigma && weights && lens && dxs && dsigma, "dx_upsample_bwd: null pointer");
+  DX_REQUIRE(Dm == D && B > 0 && L > 0 && T > 0, "dx_upsample_bwd: bad dims (D must be 128)");
+  UpBwdArgs a{dxup, xs, mu, sigma, weights, lens, dxs, dsigma, B, L, T};
+  hipStream_t s = (hipStream_t)stream;
+  if (bwd_smem<64>(L) <= LDS_BUDGET) launch_bwd<64>(a, s);
+  else if (bwd_smem<32>(L) <= LDS_BUDGET) launch_bwd<32>(a, s);
+  else { DX_REQUIRE(bwd_smem<16>(L) <= LDS_BUDGET, "dx_upsample_bwd: L=%d too long for the LDS tiles", L); launch_bwd<16>(a, s); }
+  DX_LAUNCH_CHECK("dx_upsample_bwd");
+  return DX_OK;
+}
+
+int dx_upsample_sym_bwd(const float* dxs_in, const float* dsigma, const float* xs, const float* z, const float* dur, const int* lens,
+                        const float* wd, const float* bd, const float* wr, float* dxs_out, float* dz, float* dwr, float* dbr,
+                        int B, int L, int Dm, void* stream) {
+  DX_REQUIRE(dxs_in && dsigma && xs && z && dur && lens && wd && bd && wr && dxs_out && dz && dwr && dbr, "dx_upsample_sym_bwd: null pointer");
+  DX_REQUIRE(Dm == D && B > 0 && L > 0, "dx_upsample_sym_bwd: bad dims (D must be 128)");
+  SymBwdArgs a{dxs_in, dsigma, xs, z, dur, lens, wd, bd, wr, dxs_out, dz, dwr, dbr, B, L};
+  const long rows = (long)B * L;
+  hipLaunchKernelGGL(upsample_sym_bwd_kernel, dim3((int)std::min<long>((rows + 3) / 4, 1024)), dim3(256), 0, (hipStream_t)stream, a);
+  DX_LAUNCH_CHECK("dx_upsample_sym_bwd");
+  return DX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,331 @@
+"""Tensor-level wrappers over the C ABI (include/daft_exprt_hip.h).
+
+PyTorch is used for device memory (caching allocator), the current HIP stream and autograd bookkeeping only; all
+arithmetic on the path is done by libdaft_exprt_hip.so.  Every wrapper launches on ``torch.cuda.current_stream()``.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from ._lib import lib
+
+_PRECISION = {'bf16': 0}
+
+
+def set_precision(name: str) -> None:
+    """'f32': exact-f32 MFMA operands (parity mode).  'bf16': bf16 MFMA operands, fp32 accumulate (throughput mode)."""
+    if name not in ('f32', 'bf16'):
+        raise ValueError(f"precision must be 'f32' or 'bf16', got {name!r}")
+    _PRECISION['bf16'] = 1 if name == 'bf16' else 0
+
+
+def get_precision() -> str:
+    return 'bf16' if _PRECISION['bf16'] else 'f32'
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name):
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise TypeError(f'{name} must be a float32 tensor on the GPU (got {t.dtype} on {t.device})')
+    return t
+
+
+def _rows(t):
+    """(B, N, C)-shaped tensor whose last dim is contiguous -> (ld, C); rows must be uniformly strided."""
+    if t.stride(-1) != 1:
+        raise ValueError('last dimension must be contiguous')
+    ld = t.stride(-2)
+    if t.dim() == 3 and t.stride(0) != t.shape[1] * ld:
+        raise ValueError('batch rows must be densely stacked')
+    return ld
+
+
+class PackedWeight:
+    """MFMA-ready copies of one (Cout, Cin[, taps]) parameter, refreshed when the parameter (or the precision) changes."""
+
+    def __init__(self, weight: torch.Tensor):
+        self.weight = weight
+        self.cout, self.cin = weight.shape[0], weight.shape[1]
+        self.taps = weight.shape[2] if weight.dim() == 3 else 1
+        self._key = None
+        self.fwd = self.bwd = None
+        self.bf16 = 0
+
+    def refresh(self):
+        w = self.weight
+        key = (w._version, w.data_ptr(), _PRECISION['bf16'])
+        if key == self._key:
+            return self
+        bf16 = _PRECISION['bf16']
+        dims = (ctypes.c_int * 4)()
+        lib().dx_pack_dims(self.cout, self.cin, bf16, ctypes.cast(dims, ctypes.c_void_p))
+        dt = torch.bfloat16 if bf16 else torch.float32
+        if self.fwd is None or self.fwd.dtype != dt:
+            self.fwd = torch.empty(self.taps * int(dims[0]) * int(dims[1]), dtype=dt, device=w.device)
+            self.bwd = torch.empty(self.taps * int(dims[2]) * int(dims[3]), dtype=dt, device=w.device)
+        lib().dx_pack_weights(_p(w.detach()), _p(self.fwd), _p(self.bwd), self.cout, self.cin, self.taps, bf16, _stream())
+        self.bf16 = bf16
+        self._key = key
+        return self
+
+
+def conv_gemm(x, pack: PackedWeight, bias=None, *, transpose=False, relu=False, post_scale=None, post_shift=None,
+              relu_aux=None, out=None, accumulate=False, lens=None, mask_rows=False, out_scale=1.0, B=None, N=None):
+    """y = epilogue(conv(x)).  ``transpose=True`` runs the input-gradient convolution (x is dY, result is dX)."""
+    _chk(x, 'x')
+    pack.refresh()
+    if x.dim() == 2:
+        B_, N_ = (1, x.shape[0]) if B is None else (B, N)
+    else:
+        B_, N_ = x.shape[0], x.shape[1]
+    cin, cout = (pack.cout, pack.cin) if transpose else (pack.cin, pack.cout)
+    if x.shape[-1] != cin:
+        raise ValueError(f'expected {cin} input channels, got {x.shape[-1]}')
+    ldx = _rows(x)
+    if out is None:
+        out = torch.empty(*x.shape[:-1], cout, dtype=torch.float32, device=x.device)
+    ldy = _rows(out)
+    lib().dx_conv_gemm(_p(x), ldx, _p(pack.bwd if transpose else pack.fwd), _p(bias), _p(out), ldy, B_, N_, cin, cout, pack.taps,
+                       pack.bf16, int(relu), _p(post_scale), _p(post_shift), _p(relu_aux),
+                       0 if relu_aux is None else _rows(relu_aux), int(accumulate), _p(lens), int(mask_rows), float(out_scale), _stream())
+    return out
+
+
+def conv_wgrad(dy, x, pack: PackedWeight):
+    """Gradient w.r.t. the (Cout, Cin[, taps]) parameter, in the parameter's own layout."""
+    B_, N_ = (1, x.shape[0]) if x.dim() == 2 else (x.shape[0], x.shape[1])
+    g = torch.zeros(pack.taps * pack.cout * pack.cin, dtype=torch.float32, device=x.device)
+    lib().dx_conv_wgrad(_p(dy), _rows(dy), _p(x), _rows(x), _p(g), B_, N_, pack.cin, pack.cout, pack.taps, _stream())
+    if pack.taps == 1:
+        return g.view(pack.weight.shape)
+    grad = torch.empty(pack.weight.shape, dtype=torch.float32, device=x.device)
+    lib().dx_unpack_wgrad(_p(g), _p(grad), pack.cout, pack.cin, pack.taps, 0, _stream())
+    return grad
+
+
+def colsum(x, C=None):
+    C = x.shape[-1] if C is None else C
+    rows = x.numel() // x.shape[-1]
+    out = torch.zeros(C, dtype=torch.float32, device=x.device)
+    lib().dx_colsum(_p(x), _rows(x), _p(out), rows, C, _stream())
+    return out
+
+
+def attention_fwd(qkv, lens, heads, seed, p_drop):
+    B, N, D3 = qkv.shape
+    D = D3 // 3
+    ctx = torch.empty(B, N, D, dtype=torch.float32, device=qkv.device)
+    lse = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device)
+    lib().dx_attention_fwd(_p(qkv), _rows(qkv), _p(lens), _p(ctx), D, _p(lse), B, N, heads, D, seed, float(p_drop), _stream())
+    return ctx, lse
+
+
+def attention_bwd(qkv, ctx, dctx, lse, lens, heads, seed, p_drop):
+    B, N, D3 = qkv.shape
+    D = D3 // 3
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device)
+    lib().dx_attention_bwd(_p(qkv), _rows(qkv), _p(ctx), _p(dctx), _rows(dctx), _p(lse), _p(delta), _p(lens), _p(dqkv), _rows(dqkv),
+                           B, N, heads, D, seed, float(p_drop), _stream())
+    return dqkv
+
+
+def ln_fwd(a, res, w, b, film, lens, *, seed_pre=0, p_pre=0.0, seed_post=0, p_post=0.0):
+    """In place on ``a`` (becomes z = drop(a) + res).  Returns (y, mean, rstd)."""
+    B, N, C = a.shape
+    y = torch.empty_like(a)
+    mean = torch.empty(B, N, dtype=torch.float32, device=a.device)
+    rstd = torch.empty(B, N, dtype=torch.float32, device=a.device)
+    lib().dx_ln_fwd(_p(a), _p(res), _p(w), _p(b), _p(film), 0 if film is None else film.stride(0), _p(lens), _p(y), _p(mean), _p(rstd),
+                    B, N, C, seed_pre, float(p_pre), seed_post, float(p_post), _stream())
+    return y, mean, rstd
+
+
+def ln_bwd(dy, z, mean, rstd, w, b, film, lens, *, relu_mask=False, want_da=False, seed_pre=0, p_pre=0.0, seed_post=0, p_post=0.0):
+    """Returns (dz, da or None, dw, db, dfilm or None)."""
+    B, N, C = z.shape
+    dz = torch.empty_like(z)
+    da = torch.empty_like(z) if want_da else None
+    dw = torch.zeros(C, dtype=torch.float32, device=z.device)
+    db = torch.zeros(C, dtype=torch.float32, device=z.device)
+    dfilm = torch.zeros(B, 2 * C, dtype=torch.float32, device=z.device) if film is not None else None
+    lib().dx_ln_bwd(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(film), 0 if film is None else film.stride(0), _p(lens),
+                    _p(dz), _p(da), _p(dw), _p(db), _p(dfilm), 2 * C, B, N, C, int(relu_mask),
+                    seed_pre, float(p_pre), seed_post, float(p_post), _stream())
+    return dz, da, dw, db, dfilm
+
+
+def add_pos(x, sym, emb, pe, lens):
+    if emb is not None:
+        B, N = sym.shape
+        D = emb.shape[1]
+    else:
+        B, N, D = x.shape
+    out = torch.empty(B, N, D, dtype=torch.float32, device=pe.device)
+    lib().dx_add_pos(_p(x), _p(sym), _p(emb), _p(pe), _p(lens), _p(out), B, N, D, pe.shape[0], _stream())
+    return out
+
+
+def mask_rows(x, lens):
+    B, N, C = x.shape
+    out = torch.empty_like(x)
+    lib().dx_mask_rows(_p(x), _p(lens), _p(out), B, N, C, _stream())
+    return out
+
+
+def embedding_bwd(dout, sym, lens, n_rows):
+    B, N, D = dout.shape
+    demb = torch.zeros(n_rows, D, dtype=torch.float32, device=dout.device)
+    lib().dx_embedding_bwd(_p(dout), _p(sym), _p(lens), _p(demb), B, N, D, _stream())
+    return demb
+
+
+def accent_sum(prenet, energy, pitch, we, be, wp, bp, pe, lens):
+    B, N, D = prenet.shape
+    out = torch.empty_like(prenet)
+    lib().dx_accent_sum(_p(prenet), _p(energy), _p(pitch), _p(we), _p(be), _p(wp), _p(bp), _p(pe), _p(lens), _p(out), B, N, D, pe.shape[0], _stream())
+    return out
+
+
+def scalar_conv_wgrad(dout, s0, s1, lens, rowscale=None):
+    """Gradients of Conv1d(1->128, k=3) weights/biases fed by the scalar streams s0 (and s1) given dout (B, N, 128)."""
+    B, N = s0.shape
+    D = 128
+    dev = s0.device
+    dw0 = torch.zeros(D, 1, 3, dtype=torch.float32, device=dev)
+    db0 = torch.zeros(D, dtype=torch.float32, device=dev)
+    dw1 = torch.zeros(D, 1, 3, dtype=torch.float32, device=dev) if s1 is not None else None
+    db1 = torch.zeros(D, dtype=torch.float32, device=dev) if s1 is not None else None
+    ldd = dout.stride(-2) if dout.dim() == 3 else 0  # a 1-D dout (D,) is broadcast over every row
+    lib().dx_scalar_conv_wgrad(_p(dout), ldd, _p(rowscale), _p(s0), _p(s1), _p(lens), _p(dw0), _p(db0), _p(dw1), _p(db1), B, N, D, _stream())
+    return dw0, db0, dw1, db1
+
+
+def mean_pool(x, lens):
+    B, N, C = x.shape
+    out = torch.zeros(B, C, dtype=torch.float32, device=x.device)
+    lib().dx_mean_pool(_p(x), _p(lens), _p(out), B, N, C, _stream())
+    return out
+
+
+def mean_pool_bwd(dout, lens, N):
+    B, C = dout.shape
+    dx = torch.empty(B, N, C, dtype=torch.float32, device=dout.device)
+    lib().dx_mean_pool_bwd(_p(dout), _p(lens), _p(dx), B, N, C, _stream())
+    return dx
+
+
+def transpose(x):
+    """(B, R, C) -> (B, C, R), contiguous."""
+    B, R, C = x.shape
+    out = torch.empty(B, C, R, dtype=torch.float32, device=x.device)
+    lib().dx_transpose(_p(x), _p(out), B, R, C, _stream())
+    return out
+
+
+def l2_normalize(x):
+    y = torch.empty_like(x)
+    lib().dx_l2_normalize(_p(x), _p(y), x.shape[0], x.shape[1], _stream())
+    return y
+
+
+def cross_entropy(logits, target):
+    B, S = logits.shape
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty_like(logits)
+    lib().dx_cross_entropy(_p(logits), _p(target), _p(loss), _p(dlogits), B, S, _stream())
+    return loss, dlogits
+
+
+def duration_scan(dur_int):
+    B, L = dur_int.shape
+    mu = torch.empty(B, L, dtype=torch.float32, device=dur_int.device)
+    totals = torch.empty(B, dtype=torch.long, device=dur_int.device)
+    lib().dx_duration_scan(_p(dur_int), _p(mu), _p(totals), B, L, _stream())
+    return mu, totals
+
+
+def upsample_prep(enc, dur, energy, pitch, wd, bd, we, be, wp, bp, wr, br, lens):
+    B, L, D = enc.shape
+    xs = torch.empty_like(enc)
+    z = torch.empty(B, L, dtype=torch.float32, device=enc.device)
+    sigma = torch.empty(B, L, dtype=torch.float32, device=enc.device)
+    lib().dx_upsample_prep(_p(enc), _p(dur), _p(energy), _p(pitch), _p(wd), _p(bd), _p(we), _p(be), _p(wp), _p(bp), _p(wr), _p(br),
+                           _p(lens), _p(xs), _p(z), _p(sigma), B, L, D, _stream())
+    return xs, z, sigma
+
+
+def upsample_fwd(xs, mu, sigma, lens, T):
+    B, L, D = xs.shape
+    weights = torch.empty(B, L, T, dtype=torch.float32, device=xs.device)
+    xup = torch.empty(B, T, D, dtype=torch.float32, device=xs.device)
+    lib().dx_upsample_fwd(_p(xs), _p(mu), _p(sigma), _p(lens), _p(weights), _p(xup), B, L, T, D, _stream())
+    return xup, weights
+
+
+def upsample_bwd(dxup, xs, mu, sigma, weights, lens):
+    B, L, D = xs.shape
+    T = weights.shape[2]
+    dxs = torch.zeros_like(xs)
+    dsigma = torch.zeros(B, L, dtype=torch.float32, device=xs.device)
+    lib().dx_upsample_bwd(_p(dxup), _p(xs), _p(mu), _p(sigma), _p(weights), _p(lens), _p(dxs), _p(dsigma), B, L, T, D, _stream())
+    return dxs, dsigma
+
+
+def upsample_sym_bwd(dxs, dsigma, xs, z, dur, lens, wd, bd, wr):
+    B, L, D = xs.shape
+    dxs_out = torch.empty_like(xs)
+    dz = torch.empty(B, L, dtype=torch.float32, device=xs.device)
+    dwr = torch.zeros(D, dtype=torch.float32, device=xs.device)
+    dbr = torch.zeros(1, dtype=torch.float32, device=xs.device)
+    lib().dx_upsample_sym_bwd(_p(dxs), _p(dsigma), _p(xs), _p(z), _p(dur), _p(lens), _p(wd), _p(bd), _p(wr), _p(dxs_out), _p(dz), _p(dwr), _p(dbr),
+                              B, L, D, _stream())
+    return dxs_out, dz, dwr, dbr
+
+
+def mel_stats(mel_pred, mel_target):
+    B, M, T = mel_pred.shape
+    dev = mel_pred.device
+    ep = torch.empty(B, T, dtype=torch.float32, device=dev)
+    et = torch.empty(B, T, dtype=torch.float32, device=dev)
+    sums = torch.zeros(2, B, dtype=torch.float32, device=dev)
+    lib().dx_mel_stats(_p(mel_pred), _p(mel_target), _p(ep), _p(et), _p(sums[0]), _p(sums[1]), B, M, T, _stream())
+    return ep, et, sums
+
+
+def energy_diff(ep, et, lens):
+    B, T = ep.shape
+    des = torch.empty_like(ep)
+    esum = torch.zeros(1, dtype=torch.float32, device=ep.device)
+    lib().dx_energy_diff(_p(ep), _p(et), _p(lens), _p(des), _p(esum), B, T, _stream())
+    return des, esum
+
+
+def mel_grad(mel_pred, mel_target, ep, des, lens, c_l1, c_l2, c_e):
+    B, M, T = mel_pred.shape
+    dmel = torch.empty_like(mel_pred)
+    lib().dx_mel_grad(_p(mel_pred), _p(mel_target), _p(ep), _p(des), _p(lens), float(c_l1), float(c_l2), float(c_e), _p(dmel), B, M, T, _stream())
+    return dmel
+
+
+def pitch_mse(pp, gt, lens):
+    B, T = gt.shape
+    sums = torch.zeros(2, dtype=torch.float32, device=gt.device)
+    lib().dx_pitch_mse(_p(pp), _p(gt), _p(lens), _p(sums), B, T, _stream())
+    return sums
+
+
+def pitch_grad(pp, gt, lens, sums, scale):
+    B, T = gt.shape
+    dpp = torch.empty(B, T, dtype=torch.float32, device=gt.device)
+    lib().dx_pitch_grad(_p(pp), _p(gt), _p(lens), _p(sums), float(scale), _p(dpp), B, T, _stream())
+    return dpp
