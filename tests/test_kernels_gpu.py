@@ -36,7 +36,7 @@ def ref_conv(x, w, b, taps):
     return F.conv1d(x.transpose(1, 2), w, b, padding=1).transpose(1, 2)
 
 
-@pytest.mark.parametrize('precision,tol', [('f32', 2e-6), ('bf16', 2e-2)])
+@pytest.mark.parametrize('precision,tol', [('f32', 5e-6), ('bf16', 2e-2)])
 @pytest.mark.parametrize('B,N,Cin,Cout,taps', [(3, 150, 80, 1024, 3), (2, 129, 1024, 128, 3), (4, 37, 128, 384, 1),
                                                 (5, 1, 192, 128, 1), (2, 300, 128, 80, 1), (3, 17, 128, 3, 1)])
 def test_conv_gemm_forward_dgrad_wgrad(ops, precision, tol, B, N, Cin, Cout, taps):
@@ -305,7 +305,7 @@ def test_gaussian_upsampler(ops, B, L, lens, dur_hi):
     T = int(totals.max())
     assert T == xup_ref.shape[1]
     xup, w = ops.upsample_fwd(xs, mu, sigma, lens_d, T)
-    assert (w.cpu() - w_ref).abs().max() < 2e-6
+    assert (w.cpu() - w_ref).abs().max() < 1e-5
     assert rel_err(xup.cpu(), xup_ref.detach()) < 5e-6
     dx = torch.randn(B, T, D, generator=g)
     xup_ref.backward(dx)

@@ -410,6 +410,24 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
   if (threadIdx.x == 0) loss[0] = part[0] / (float)B;
 }
 
+// out = dy * (y > 0)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+// out[row][c] = x[row][c] * scale[c] + shift[c]     (eval-mode BatchNorm of the frozen pitch predictor)
+__global__ __launch_bounds__(256) void channel_affine_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             float* __restrict__ out, long rows, int C) {
+  const long total4 = rows * C / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const int c = (int)((i * 4) % C);
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+    reinterpret_cast<float4*>(out)[i] = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+  }
+}
+
 inline int row_grid(long rows) { return (int)std::min<long>((rows + 3) / 4, 8192); }
 
 }  // namespace
@@ -544,6 +562,21 @@ int dx_cross_entropy(const float* logits, const long* target, float* loss, float
   DX_REQUIRE(logits && target && loss && dlogits && B > 0 && S > 0, "dx_cross_entropy: bad arguments");
   hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, target, loss, dlogits, B, S);
   DX_LAUNCH_CHECK("dx_cross_entropy");
+  return DX_OK;
+}
+
+int dx_relu_bwd(const float* dy, const float* y, float* out, long n, void* stream) {
+  DX_REQUIRE(dy && y && out && n > 0, "dx_relu_bwd: bad arguments");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3((int)std::min<long>((n + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream, dy, y, out, n);
+  DX_LAUNCH_CHECK("dx_relu_bwd");
+  return DX_OK;
+}
+
+int dx_channel_affine(const float* x, const float* scale, const float* shift, float* out, long rows, int C, void* stream) {
+  DX_REQUIRE(x && scale && shift && out && rows > 0 && C > 0 && (C % 4) == 0, "dx_channel_affine: bad arguments");
+  const long total4 = rows * C / 4;
+  hipLaunchKernelGGL(channel_affine_kernel, dim3((int)std::min<long>((total4 + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, out, rows, C);
+  DX_LAUNCH_CHECK("dx_channel_affine");
   return DX_OK;
 }
 

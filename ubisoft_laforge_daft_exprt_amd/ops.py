@@ -329,3 +329,15 @@ def pitch_grad(pp, gt, lens, sums, scale):
     dpp = torch.empty(B, T, dtype=torch.float32, device=gt.device)
     lib().dx_pitch_grad(_p(pp), _p(gt), _p(lens), _p(sums), float(scale), _p(dpp), B, T, _stream())
     return dpp
+
+
+def relu_bwd(dy, y):
+    out = torch.empty_like(dy)
+    lib().dx_relu_bwd(_p(dy), _p(y), _p(out), dy.numel(), _stream())
+    return out
+
+
+def channel_affine(x, scale, shift):
+    out = torch.empty_like(x)
+    lib().dx_channel_affine(_p(x), _p(scale), _p(shift), _p(out), x.numel() // x.shape[-1], x.shape[-1], _stream())
+    return out
