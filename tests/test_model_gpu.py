@@ -1,0 +1,200 @@
+"""End-to-end parity of the HIP path (through the C ABI) against the golden fixtures written by the reference, and against
+the CPU oracle on larger seeded batches.  fp32 operands (``set_precision('f32')``); tolerance target from BASELINE.json:
+mean |mel - mel_ref| <= 1e-4 over valid frames (we assert 2e-5), integer paths bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def dx():
+    import ubisoft_laforge_daft_exprt_amd as pkg
+    pkg.set_precision('f32')
+    return pkg
+
+
+def build_model(dx, hp, drop=()):
+    model = dx.DaftExprt(hp).to(DEV)
+    model.load_state_dict({k: v for k, v in helpers.golden_state_dict(drop).items()}, strict=True)
+    return model
+
+
+def build_loss(dx, hp):
+    crit = dx.DaftExprtLoss(DEV, hp)
+    if hp.pitch_consistency_weight > 0:
+        crit.load_pitch_predictor(helpers.golden_pitch_predictor_state_dict())
+    return crit
+
+
+def _hp_for(name):
+    if name == 'train_no_postmult':
+        return helpers.golden_hparams(post_mult_weight=0.0, energy_consistency_weight=0.0, pitch_consistency_weight=0.0)
+    return helpers.golden_hparams()
+
+
+def valid_mel_l1(mel, ref, out_lens):
+    tot, cnt = 0.0, 0
+    for b, n in enumerate(out_lens.tolist()):
+        tot += np.abs(mel[b, :, :n] - ref[b, :, :n]).sum()
+        cnt += mel.shape[1] * n
+    return tot / cnt
+
+
+@pytest.mark.parametrize('name', ['train_halo', 'train_zero_dur', 'train_single', 'train_no_postmult'])
+def test_forward_loss_vs_golden(dx, name):
+    case = helpers.load_case(name)
+    hp = _hp_for(name)
+    model = build_model(dx, hp, ('style_adapter.post_multipliers',) if name == 'train_no_postmult' else ())
+    model.eval()
+    inputs, targets = helpers.case_inputs(case, DEV)
+    with torch.no_grad():
+        outputs = model(inputs)
+        total, terms = build_loss(dx, hp)(outputs, targets, int(case['meta/iteration']))
+    spk_preds, film, _, (mel, out_lens), weights = outputs
+    mel, weights = mel.cpu().numpy(), weights.cpu().numpy()
+    assert mel.shape == case['out/mel'].shape and weights.shape == case['out/weights'].shape   # T_max: exact
+    assert valid_mel_l1(mel, case['out/mel'], out_lens.cpu()) < 2e-5
+    np.testing.assert_allclose(mel, case['out/mel'], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(weights, case['out/weights'], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(spk_preds.cpu().numpy(), case['out/speaker_preds'], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(film[3].cpu().numpy(), case['out/film_dec'], rtol=0, atol=5e-5)
+    for b, n in enumerate(out_lens.tolist()):
+        assert (mel[b, :, n:] == 0).all()                                    # padded outputs are exactly zero
+    ref_total = float(case['loss/total'])
+    assert abs(total.item() - ref_total) <= 2e-5 * abs(ref_total)
+    for k, v in terms.items():
+        ref = float(case['loss/' + k])
+        assert abs(v - ref) <= 5e-5 * max(1.0, abs(ref)), (k, v, ref)
+
+
+@pytest.mark.parametrize('name', ['train_halo', 'train_single'])
+def test_gradients_vs_golden(dx, name):
+    case = helpers.load_case(name)
+    hp = _hp_for(name)
+    model = build_model(dx, hp)
+    model.train()                                                            # dropout p = 0 in the golden hparams
+    inputs, targets = helpers.case_inputs(case, DEV)
+    outputs = model(inputs)
+    total, _ = build_loss(dx, hp)(outputs, targets, int(case['meta/iteration']))
+    total.backward()
+    worst = (0.0, None)
+    for k, p in model.named_parameters():
+        assert p.grad is not None, k
+        assert torch.isfinite(p.grad).all(), k
+        s, a, smp = helpers.sample_like_golden(p.grad)
+        ref_a = float(case['grad_abs/' + k])
+        ref_smp = case['grad_smp/' + k]
+        scale = max(float(np.abs(ref_smp).max()), 1e-8)
+        err = float(np.abs(smp - ref_smp).max()) / scale
+        if err > worst[0]:
+            worst = (err, k)
+        assert abs(a - ref_a) <= 1e-3 * max(ref_a, 1e-6), (k, a, ref_a)
+        assert err <= 2e-3, (k, err)
+    print('worst sampled-gradient relative error', worst)
+
+
+def test_forward_backward_vs_oracle_c1(dx):
+    """C1-shaped batch (B=4, L<=100, T up to ~800): the oracle runs in a few seconds on CPU."""
+    from oracle import daft_exprt_oracle as oracle
+    from ubisoft_laforge_daft_exprt_amd.synth import CONFIGS, synthetic_batch
+    hp = helpers.golden_hparams()
+    batch = synthetic_batch(n_speakers=hp.n_speakers, zero_dur_frac=0.1, **CONFIGS['C1'])
+    model = build_model(dx, hp)
+    model.train()
+    inputs, targets = model.parse_batch(DEV, batch)
+    targets = targets + (inputs[6], inputs[7])
+    outputs = model(inputs)
+    crit = build_loss(dx, hp)
+    total, terms = crit(outputs, targets, 4000)
+    total.backward()
+    sd = helpers.golden_state_dict()
+    for v in sd.values():
+        v.requires_grad_(True)
+    cpu_inputs = tuple(batch[i] for i in range(11)) + (batch[13],)
+    cpu_targets = (batch[1], batch[3], batch[4], batch[8], batch[9], batch[10], batch[6], batch[7])
+    ref_out = oracle.forward(sd, cpu_inputs, hp, training=True)
+    ref_total, ref_terms = oracle.loss(ref_out, cpu_targets, 4000, hp, helpers.golden_pitch_predictor_state_dict())
+    ref_total.backward()
+    mel, ref_mel = outputs[3][0].detach().cpu().numpy(), ref_out[3][0].detach().numpy()
+    assert mel.shape == ref_mel.shape
+    l1 = valid_mel_l1(mel, ref_mel, batch[9])
+    print('valid mel L1 vs oracle', l1)
+    assert l1 < 2e-5
+    assert np.abs(outputs[4].cpu().numpy() - ref_out[4].detach().numpy()).max() < 2e-4
+    assert abs(total.item() - ref_total.item()) <= 2e-5 * abs(ref_total.item())
+    for k, v in terms.items():
+        assert abs(v - float(ref_terms[k])) <= 5e-5 * max(1.0, abs(float(ref_terms[k]))), k
+    worst = (0.0, None)
+    for k, p in model.named_parameters():
+        g, r = p.grad.detach().cpu(), sd[k].grad
+        err = ((g - r).abs().max() / r.abs().max().clamp_min(1e-10)).item()
+        if err > worst[0]:
+            worst = (err, k)
+        assert err < 3e-3, (k, err)
+    print('worst gradient relative error vs oracle', worst)
+
+
+@pytest.mark.parametrize('name,transform', [('inference_add', 'add'), ('inference_multiply', 'multiply')])
+def test_inference_vs_golden(dx, name, transform):
+    case = helpers.load_case(name)
+    hp = helpers.golden_hparams(stats={'spk 0': {'pitch': {'mean': 5.0, 'std': 0.25}}, 'spk 1': {'pitch': {'mean': 4.6, 'std': 0.3}}})
+    model = build_model(dx, hp).eval()
+    t = lambda k: torch.from_numpy(case[k]).clone().to(DEV)
+    inputs = (t('in/symbols'), t('in/dur_factors'), t('in/energy_factors'), t('in/pitch_factors'), t('in/input_lengths'), t('in/speaker_ids'))
+    prosody = {k: t('in/prosody_' + k) for k in ('duration_preds', 'durations_int', 'energy_preds', 'pitch_preds')}
+    with torch.no_grad():
+        enc, (mel, out_lens), weights = model.inference(inputs, transform, hp, external_prosody=prosody,
+                                                        external_embeddings=t('in/spk_embs'), external_accent_emb=t('in/accent_emb'))
+    assert np.array_equal(enc[1].cpu().numpy(), case['out/durations_int'])              # bit-exact duration rounding
+    assert np.array_equal(out_lens.cpu().numpy(), case['out/output_lengths'])
+    assert mel.shape == case['out/mel'].shape
+    np.testing.assert_allclose(enc[0].cpu().numpy(), case['out/duration_preds'], rtol=0, atol=0)
+    np.testing.assert_allclose(enc[2].cpu().numpy(), case['out/energy_preds'], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(enc[3].cpu().numpy(), case['out/pitch_preds'], rtol=0, atol=5e-6)
+    assert valid_mel_l1(mel.cpu().numpy(), case['out/mel'], out_lens.cpu()) < 2e-5
+    np.testing.assert_allclose(weights.cpu().numpy(), case['out/weights'], rtol=0, atol=1e-4)
+
+
+def test_error_behaviour(dx):
+    hp = helpers.golden_hparams()
+    model = build_model(dx, hp)
+    inputs, _ = helpers.case_inputs(helpers.load_case('train_single'), DEV)
+    with pytest.raises(ValueError):
+        model(inputs[:11])
+    with pytest.raises(ValueError):
+        model(inputs[:11] + (None,))
+    with pytest.raises(ValueError):
+        model.parse_batch(DEV, inputs)
+    with pytest.raises(ValueError):
+        model.inference(inputs[:6], 'add', hp)
+    cpu_inputs, _ = helpers.case_inputs(helpers.load_case('train_single'), 'cpu')
+    with pytest.raises(RuntimeError):
+        model(cpu_inputs)                                                    # no CPU fallback
+
+
+def test_dropout_training_step_is_finite_and_seeded(dx):
+    from ubisoft_laforge_daft_exprt_amd.synth import synthetic_batch
+    hp = dx.HyperParams(n_speakers=3)
+    model = dx.DaftExprt(hp).to(DEV)
+    model.load_state_dict(helpers.golden_state_dict(), strict=True)
+    model.train()
+    batch = synthetic_batch(6, (20, 40), seed=5, n_speakers=3)
+    inputs, targets = model.parse_batch(DEV, batch)
+    crit = build_loss(dx, hp)
+    mels = []
+    for seed in (1, 1, 2):
+        dx.manual_seed(seed)
+        model.zero_grad()
+        out = model(inputs)
+        total, _ = crit(out, targets + (inputs[6], inputs[7]), 100)
+        total.backward()
+        assert torch.isfinite(total)
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+        mels.append(out[3][0].detach().clone())
+    assert torch.equal(mels[0], mels[1])          # same seed -> same dropout masks
+    assert not torch.equal(mels[0], mels[2])

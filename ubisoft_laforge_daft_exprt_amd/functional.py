@@ -1,0 +1,295 @@
+"""Autograd glue: one ``torch.autograd.Function`` per fused block of the reference model, each a fixed sequence of
+C-ABI kernel launches (see ops.py).  Saved activations are the kernels' own outputs; dropout masks are never stored
+(the backward kernels regenerate them from the same counter-based seed).
+"""
+from __future__ import annotations
+
+import threading
+
+import torch
+
+from . import ops
+
+# ----------------------------------------------------------------------------------------------------------------------
+# dropout seeds: every dropout site of every forward call draws a fresh 64-bit stream id
+# ----------------------------------------------------------------------------------------------------------------------
+_seed_state = threading.local()
+
+
+def manual_seed(seed: int) -> None:
+    _seed_state.base = (int(seed) * 0x9E3779B97F4A7C15 + 0x1234567) & 0xFFFFFFFFFFFFFFFF
+    _seed_state.counter = 0
+
+
+def next_seed() -> int:
+    if not hasattr(_seed_state, 'base'):
+        manual_seed(torch.initial_seed())
+    _seed_state.counter += 1
+    return (_seed_state.base + _seed_state.counter * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+
+class Lengths:
+    """Valid lengths of one axis of a padded batch: int32 on the device for the kernels, Python ints for shapes."""
+
+    def __init__(self, lengths: torch.Tensor, host=None):
+        self.host = [int(v) for v in (lengths.tolist() if host is None else host)]  # one D2H sync unless given
+        self.max = max(self.host)
+        self.total = sum(self.host)
+        self.i32 = lengths.to(dtype=torch.int32).contiguous()
+        self.i64 = lengths
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Linear (LinearNorm, model.py:57-72) on (rows, Cin)
+# ----------------------------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, pack, relu, grad_scale, lens, need_dx):
+        x2 = x.reshape(-1, x.shape[-1]) if lens is None else x
+        y = ops.conv_gemm(x2, pack, bias, relu=relu, lens=lens, mask_rows=lens is not None)
+        ctx.save_for_backward(x2, y if relu else None)
+        ctx.pack, ctx.relu, ctx.grad_scale, ctx.lens, ctx.need_dx, ctx.xshape = pack, relu, grad_scale, lens, need_dx, x.shape
+        return y.view(*x.shape[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, y = ctx.saved_tensors
+        dy = dy.contiguous().view(*x2.shape[:-1], dy.shape[-1])
+        if ctx.lens is not None:
+            dy = ops.mask_rows(dy, ctx.lens)
+        if ctx.relu:
+            dy = ops.relu_bwd(dy, y)
+        dw = ops.conv_wgrad(dy, x2, ctx.pack)
+        db = ops.colsum(dy)
+        dx = None
+        if ctx.need_dx:
+            dx = ops.conv_gemm(dy, ctx.pack, None, transpose=True, out_scale=ctx.grad_scale).view(ctx.xshape)
+        return dx, dw, db, None, None, None, None, None
+
+
+class PaddedLinear:
+    """Linear whose output width is not a multiple of 4 (speaker logits): the kernels see a zero-padded (Cout4, Cin) weight."""
+
+    def __init__(self, weight, bias):
+        self.weight, self.bias = weight, bias
+        self.cout = weight.shape[0]
+        self.cout4 = (self.cout + 3) // 4 * 4
+        self._key = None
+        self.wpad = self.bpad = self.pack = None
+
+    def padded(self):
+        key = (self.weight._version, self.bias._version, self.weight.data_ptr())
+        if key != self._key:
+            w = self.weight.detach()
+            self.wpad = torch.zeros(self.cout4, w.shape[1], dtype=w.dtype, device=w.device)
+            self.wpad[:self.cout].copy_(w)
+            self.bpad = torch.zeros(self.cout4, dtype=w.dtype, device=w.device)
+            self.bpad[:self.cout].copy_(self.bias.detach())
+            self.pack = ops.PackedWeight(self.wpad)
+            self._key = key
+        return self.wpad, self.bpad, self.pack
+
+
+class PaddedLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, padded: PaddedLinear):
+        _, bpad, pack = padded.padded()
+        y = ops.conv_gemm(x, pack, bpad)
+        ctx.save_for_backward(x)
+        ctx.pack, ctx.cout = pack, padded.cout
+        return y[:, :padded.cout].contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dyp = torch.zeros(dy.shape[0], ctx.pack.cout, dtype=dy.dtype, device=dy.device)
+        dyp[:, :ctx.cout].copy_(dy)
+        dw = ops.conv_wgrad(dyp, x, ctx.pack)[:ctx.cout]
+        db = ops.colsum(dyp)[:ctx.cout]
+        dx = ops.conv_gemm(dyp, ctx.pack, None, transpose=True)
+        return dx, dw, db, None
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# FFT block (model.py:238-259): MHA + dropout + residual LN + mask, conv FF + dropout + residual LN + FiLM + mask
+# ----------------------------------------------------------------------------------------------------------------------
+class FFTBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, film, lens, packs, cfg, training,
+                in_w, in_b, out_w, out_b, ln1_w, ln1_b, c1_w, c1_b, c2_w, c2_b, ln2_w, ln2_b):
+        p_attn = cfg['attn_dropout'] if training else 0.0
+        p_conv = cfg['conv_dropout'] if training else 0.0
+        heads = cfg['attn_nb_heads']
+        s_attn, s_ln1, s_ln2 = (next_seed(), next_seed(), next_seed()) if training else (0, 0, 0)
+        film = film if film is None or film.stride(-1) == 1 else film.contiguous()
+        qkv = ops.conv_gemm(x, packs['in'], in_b)
+        att, lse = ops.attention_fwd(qkv, lens.i32, heads, s_attn, p_attn)
+        z1 = ops.conv_gemm(att, packs['out'], out_b)
+        y1, mean1, rstd1 = ops.ln_fwd(z1, x, ln1_w, ln1_b, None, lens.i32, seed_pre=s_ln1, p_pre=p_attn)
+        h = ops.conv_gemm(y1, packs['c1'], c1_b, relu=True)
+        z2 = ops.conv_gemm(h, packs['c2'], c2_b)
+        y2, mean2, rstd2 = ops.ln_fwd(z2, y1, ln2_w, ln2_b, film, lens.i32, seed_pre=s_ln2, p_pre=p_conv)
+        ctx.save_for_backward(x, film, qkv, att, lse, z1, mean1, rstd1, y1, h, z2, mean2, rstd2, ln1_w, ln1_b, ln2_w, ln2_b)
+        ctx.lens, ctx.packs, ctx.heads = lens, packs, heads
+        ctx.drop = (p_attn, p_conv, s_attn, s_ln1, s_ln2)
+        return y2
+
+    @staticmethod
+    def backward(ctx, dy2):
+        x, film, qkv, att, lse, z1, mean1, rstd1, y1, h, z2, mean2, rstd2, ln1_w, ln1_b, ln2_w, ln2_b = ctx.saved_tensors
+        lens, packs = ctx.lens, ctx.packs
+        p_attn, p_conv, s_attn, s_ln1, s_ln2 = ctx.drop
+        dy2 = dy2.contiguous()
+        dz2, da2, dln2_w, dln2_b, dfilm = ops.ln_bwd(dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, lens.i32,
+                                                      want_da=p_conv > 0, seed_pre=s_ln2, p_pre=p_conv)
+        dff = da2 if da2 is not None else dz2
+        dc2_w = ops.conv_wgrad(dff, h, packs['c2'])
+        dc2_b = ops.colsum(dff)
+        dh = ops.conv_gemm(dff, packs['c2'], None, transpose=True, relu_aux=h)
+        dc1_w = ops.conv_wgrad(dh, y1, packs['c1'])
+        dc1_b = ops.colsum(dh)
+        dy1 = ops.conv_gemm(dh, packs['c1'], None, transpose=True, out=dz2, accumulate=True)  # + residual branch
+        dz1, da1, dln1_w, dln1_b, _ = ops.ln_bwd(dy1, z1, mean1, rstd1, ln1_w, ln1_b, None, lens.i32,
+                                                  want_da=p_attn > 0, seed_pre=s_ln1, p_pre=p_attn)
+        dproj = da1 if da1 is not None else dz1
+        dout_w = ops.conv_wgrad(dproj, att, packs['out'])
+        dout_b = ops.colsum(dproj)
+        datt = ops.conv_gemm(dproj, packs['out'], None, transpose=True)
+        dqkv = ops.attention_bwd(qkv, att, datt, lse, lens.i32, ctx.heads, s_attn, p_attn)
+        din_w = ops.conv_wgrad(dqkv, x, packs['in'])
+        din_b = ops.colsum(dqkv)
+        dx = ops.conv_gemm(dqkv, packs['in'], None, transpose=True, out=dz1, accumulate=True)  # + residual branch
+        return (dx, dfilm, None, None, None, None,
+                din_w, din_b, dout_w, dout_b, dln1_w, dln1_b, dc1_w, dc1_b, dc2_w, dc2_b, dln2_w, dln2_b)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# accent-encoder front end (model.py:687-706): prenet 3 x [conv k3 -> ReLU -> LN -> dropout], + energy/pitch/position, mask
+# ----------------------------------------------------------------------------------------------------------------------
+class AccentFrontFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mel, energy, pitch, lens, packs, pe, p_drop, training,
+                c0_w, c0_b, l0_w, l0_b, c1_w, c1_b, l1_w, l1_b, c2_w, c2_b, l2_w, l2_b, we, be, wp, bp):
+        p = p_drop if training else 0.0
+        seeds = [next_seed() if training else 0 for _ in range(3)]
+        x0 = ops.transpose(mel.contiguous())                                   # (B, T, n_mel) channels-last
+        h0 = ops.conv_gemm(x0, packs['p0'], c0_b, relu=True)
+        y0, m0, r0 = ops.ln_fwd(h0, None, l0_w, l0_b, None, None, seed_post=seeds[0], p_post=p)
+        h1 = ops.conv_gemm(y0, packs['p1'], c1_b, relu=True)
+        y1, m1, r1 = ops.ln_fwd(h1, None, l1_w, l1_b, None, None, seed_post=seeds[1], p_post=p)
+        h2 = ops.conv_gemm(y1, packs['p2'], c2_b, relu=True)
+        y2, m2, r2 = ops.ln_fwd(h2, None, l2_w, l2_b, None, None, seed_post=seeds[2], p_post=p)
+        energy, pitch = energy.contiguous(), pitch.contiguous()
+        out = ops.accent_sum(y2, energy, pitch, we, be, wp, bp, pe, lens.i32)
+        ctx.save_for_backward(x0, h0, m0, r0, y0, h1, m1, r1, y1, h2, m2, r2, energy, pitch, l0_w, l0_b, l1_w, l1_b, l2_w, l2_b)
+        ctx.lens, ctx.packs, ctx.p, ctx.seeds = lens, packs, p, seeds
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x0, h0, m0, r0, y0, h1, m1, r1, y1, h2, m2, r2, energy, pitch, l0_w, l0_b, l1_w, l1_b, l2_w, l2_b = ctx.saved_tensors
+        lens, packs, p, seeds = ctx.lens, ctx.packs, ctx.p, ctx.seeds
+        dout = ops.mask_rows(dout.contiguous(), lens.i32)
+        dwe, dbe, dwp, dbp = ops.scalar_conv_wgrad(dout, energy, pitch, lens.i32)
+        dz2, _, dl2_w, dl2_b, _ = ops.ln_bwd(dout, h2, m2, r2, l2_w, l2_b, None, None, relu_mask=True, seed_post=seeds[2], p_post=p)
+        dc2_w = ops.conv_wgrad(dz2, y1, packs['p2'])
+        dc2_b = ops.colsum(dz2)
+        dy1 = ops.conv_gemm(dz2, packs['p2'], None, transpose=True)
+        dz1, _, dl1_w, dl1_b, _ = ops.ln_bwd(dy1, h1, m1, r1, l1_w, l1_b, None, None, relu_mask=True, seed_post=seeds[1], p_post=p)
+        dc1_w = ops.conv_wgrad(dz1, y0, packs['p1'])
+        dc1_b = ops.colsum(dz1)
+        dy0 = ops.conv_gemm(dz1, packs['p1'], None, transpose=True)
+        dz0, _, dl0_w, dl0_b, _ = ops.ln_bwd(dy0, h0, m0, r0, l0_w, l0_b, None, None, relu_mask=True, seed_post=seeds[0], p_post=p)
+        dc0_w = ops.conv_wgrad(dz0, x0, packs['p0'])
+        dc0_b = ops.colsum(dz0)
+        return (None, None, None, None, None, None, None, None,
+                dc0_w, dc0_b, dl0_w, dl0_b, dc1_w, dc1_b, dl1_w, dl1_b, dc2_w, dc2_b, dl2_w, dl2_b, dwe, dbe, dwp, dbp)
+
+
+class MeanPoolFn(torch.autograd.Function):
+    """sum over time / length (model.py:714)."""
+
+    @staticmethod
+    def forward(ctx, x, lens):
+        ctx.lens, ctx.N = lens, x.shape[1]
+        return ops.mean_pool(x, lens.i32)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return ops.mean_pool_bwd(dout.contiguous(), ctx.lens.i32, ctx.N), None
+
+
+class EmbedPosFn(torch.autograd.Function):
+    """mask(embedding[symbols] + position) (model.py:597-604)."""
+
+    @staticmethod
+    def forward(ctx, symbols, emb, pe, lens):
+        symbols = symbols.contiguous()
+        ctx.save_for_backward(symbols)
+        ctx.lens, ctx.rows = lens, emb.shape[0]
+        return ops.add_pos(None, symbols, emb, pe, lens.i32)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (symbols,) = ctx.saved_tensors
+        return None, ops.embedding_bwd(dout.contiguous(), symbols, ctx.lens.i32, ctx.rows), None, None
+
+
+class AddPosFn(torch.autograd.Function):
+    """mask(x + position) (model.py:554-557)."""
+
+    @staticmethod
+    def forward(ctx, x, pe, lens):
+        ctx.lens = lens
+        return ops.add_pos(x.contiguous(), None, None, pe, lens.i32)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return ops.mask_rows(dout.contiguous(), ctx.lens.i32), None, None
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Gaussian upsampling (model.py:417-510)
+# ----------------------------------------------------------------------------------------------------------------------
+class GaussianUpsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc, dur_float, dur_int, energy, pitch, lens, n_frames, wd, bd, we, be, wp, bp, wr, br):
+        dur_float, energy, pitch = dur_float.contiguous(), energy.contiguous(), pitch.contiguous()
+        xs, z, sigma = ops.upsample_prep(enc.contiguous(), dur_float, energy, pitch, wd, bd, we, be, wp, bp, wr, br, lens.i32)
+        mu, _totals = ops.duration_scan(dur_int.contiguous())
+        xup, weights = ops.upsample_fwd(xs, mu, sigma, lens.i32, n_frames)
+        ctx.save_for_backward(xs, z, sigma, mu, weights, dur_float, energy, pitch, wd, bd, wr)
+        ctx.lens = lens
+        ctx.mark_non_differentiable(weights)
+        return xup, weights
+
+    @staticmethod
+    def backward(ctx, dxup, _dweights):
+        xs, z, sigma, mu, weights, dur_float, energy, pitch, wd, bd, wr = ctx.saved_tensors
+        lens = ctx.lens
+        dxs, dsigma = ops.upsample_bwd(dxup.contiguous(), xs, mu, sigma, weights, lens.i32)
+        dxs, dz, dwr, dbr = ops.upsample_sym_bwd(dxs, dsigma, xs, z, dur_float, lens.i32, wd, bd, wr)
+        dwe, dbe, dwp, dbp = ops.scalar_conv_wgrad(dxs, energy, pitch, lens.i32)
+        dwd, dbd, _, _ = ops.scalar_conv_wgrad(wr.reshape(-1), dur_float, None, lens.i32, rowscale=dz)
+        denc = ops.mask_rows(dxs, lens.i32)  # the encoder output is zero-masked; rows >= len carry no gradient upstream
+        return denc, None, None, None, None, None, None, dwd, dbd, dwe, dbe, dwp, dbp, dwr.view(1, -1), dbr
+
+
+class MelProjectionFn(torch.autograd.Function):
+    """Linear(D -> n_mel) + mask + transpose to (B, n_mel, T) (model.py:561-563)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, pack, lens):
+        mel_cl = ops.conv_gemm(x, pack, bias, lens=lens.i32, mask_rows=True)
+        ctx.save_for_backward(x)
+        ctx.pack, ctx.lens = pack, lens
+        return ops.transpose(mel_cl)
+
+    @staticmethod
+    def backward(ctx, dmel):
+        (x,) = ctx.saved_tensors
+        d_cl = ops.mask_rows(ops.transpose(dmel.contiguous()), ctx.lens.i32)
+        dw = ops.conv_wgrad(d_cl, x, ctx.pack)
+        db = ops.colsum(d_cl)
+        dx = ops.conv_gemm(d_cl, ctx.pack, None, transpose=True)
+        return dx, dw, db, None, None

@@ -1,0 +1,161 @@
+"""``DaftExprtLoss`` with the reference's interface (src/daft_exprt/loss.py:11-159), computed by fused HIP reductions.
+
+``DaftExprtLoss(device, hparams)(outputs, targets, iteration) -> (loss, dict of 7 floats)``.  All seven terms are reduced
+on the device and fetched with ONE host transfer (the reference issues seven ``.item()`` syncs, loss.py:149-157).
+The gradient w.r.t. the predicted mel, the speaker logits and the post-multipliers is produced in the same pass and
+handed to autograd by ``_LossFn``.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import ops
+from .functional import Lengths
+
+
+def fold_pitch_predictor(state_dict, device):
+    """Frozen PitchPredictor (layers/pitch_predictor.py:38-74) -> plain conv weights: weight_norm (w = g v / ||v||, norm over
+    (in, k) per output channel) folded into the weight, eval-mode BatchNorm1d folded into a per-channel scale/shift."""
+    layers = []
+    for conv_idx, bn_idx in ((0, 2), (4, 6), (8, 10), (12, None)):
+        pre = f'conv_layers.{conv_idx}.conv.'
+        if pre + 'weight_v' in state_dict:
+            v, g = state_dict[pre + 'weight_v'].float(), state_dict[pre + 'weight_g'].float()
+            w = v * (g / v.norm(dim=(1, 2), keepdim=True))
+        elif pre + 'parametrizations.weight.original1' in state_dict:
+            v, g = state_dict[pre + 'parametrizations.weight.original1'].float(), state_dict[pre + 'parametrizations.weight.original0'].float()
+            w = v * (g / v.norm(dim=(1, 2), keepdim=True))
+        else:
+            w = state_dict[pre + 'weight'].float()
+        b = state_dict[pre + 'bias'].float()
+        layer = {'w': w.to(device).contiguous(), 'b': b.to(device).contiguous(), 'scale': None, 'shift': None}
+        if bn_idx is not None:
+            bn = f'conv_layers.{bn_idx}.'
+            scale = state_dict[bn + 'weight'].float() / torch.sqrt(state_dict[bn + 'running_var'].float() + 1e-5)
+            shift = state_dict[bn + 'bias'].float() - state_dict[bn + 'running_mean'].float() * scale
+            layer['scale'], layer['shift'] = scale.to(device).contiguous(), shift.to(device).contiguous()
+            layer['zeros'] = torch.zeros_like(layer['shift'])
+        layers.append(layer)
+    # the last conv has ONE output channel; the kernels want Cout % 4 == 0 -> zero-pad to 4 rows
+    last = layers[-1]
+    wpad = torch.zeros(4, *last['w'].shape[1:], device=device)
+    wpad[:1] = last['w']
+    bpad = torch.zeros(4, device=device)
+    bpad[:1] = last['b']
+    last['w'], last['b'] = wpad, bpad
+    for layer in layers:
+        layer['pack'] = ops.PackedWeight(layer['w'])
+    return layers
+
+
+class _LossFn(torch.autograd.Function):
+    """total = w_spk * CE + pmw * ||pm||_2 + msw * (L1 + L2) + ecw * E + pcw * P; gradients computed in the forward."""
+
+    @staticmethod
+    def forward(ctx, mel_pred, speaker_preds, post_multipliers, mel_target, speaker_ids, frames_pitch, lens: Lengths, cfg, pitch_layers):
+        dev = mel_pred.device
+        B, M, T = mel_pred.shape
+        mel_pred, mel_target = mel_pred.contiguous(), mel_target.contiguous()
+        terms = torch.zeros(7, dtype=torch.float32, device=dev)   # speaker_loss, ce_raw, post_mult, l1, l2, energy, pitch
+        d_spk = d_pm = None
+        if speaker_preds is not None:
+            ce, dlogits = ops.cross_entropy(speaker_preds.contiguous(), speaker_ids.contiguous())
+            terms[1:2] = ce
+            terms[0:1] = cfg['spk_weight'] * ce
+            d_spk = dlogits * cfg['spk_weight']
+        if post_multipliers is not None:
+            nrm = torch.linalg.vector_norm(post_multipliers.detach())      # 16 numbers
+            terms[2:3] = cfg['pmw'] * nrm
+            d_pm = cfg['pmw'] * post_multipliers.detach() / nrm
+        ep, et, sums = ops.mel_stats(mel_pred, mel_target)
+        denom = float(M) * lens.i32.float()
+        terms[3:4] = cfg['msw'] * (sums[0] / denom).mean()
+        terms[4:5] = cfg['msw'] * (sums[1] / denom).mean()
+        des, c_e = None, 0.0
+        if cfg['ecw'] > 0:
+            des, esum = ops.energy_diff(ep, et, lens.i32)
+            terms[5:6] = esum / float(lens.total)
+            c_e = cfg['ecw'] / float(lens.total)
+        dmel = ops.mel_grad(mel_pred, mel_target, ep, des, lens.i32, cfg['msw'] / (M * B), cfg['msw'] / (M * B), c_e)
+        if pitch_layers is not None and frames_pitch is not None and cfg['pcw'] > 0:
+            # frozen predictor on the predicted mel, channels-last; gradient flows through it to the mel only
+            x = ops.transpose(mel_pred)                                          # (B, T, M)
+            acts = []
+            for layer in pitch_layers[:-1]:
+                r = ops.conv_gemm(x, layer['pack'], layer['b'], relu=True)
+                acts.append(r)
+                x = ops.channel_affine(r, layer['scale'], layer['shift'])
+            last = pitch_layers[-1]
+            pp = ops.conv_gemm(x, last['pack'], last['b'])[:, :, 0].contiguous()  # (B, T)
+            frames_pitch = frames_pitch.contiguous()
+            psum = ops.pitch_mse(pp, frames_pitch, lens.i32)
+            terms[6:7] = psum[0] / (psum[1] + 1e-5)
+            dpp = ops.pitch_grad(pp, frames_pitch, lens.i32, psum, cfg['pcw'])
+            g = torch.zeros(B, T, 4, dtype=torch.float32, device=dev)
+            g[:, :, 0] = dpp
+            # each input-gradient GEMM applies the previous layer's BatchNorm scale and ReLU mask in its epilogue
+            for k in range(len(pitch_layers) - 1, 0, -1):
+                prev = pitch_layers[k - 1]
+                g = ops.conv_gemm(g, pitch_layers[k]['pack'], None, transpose=True, post_scale=prev['scale'], post_shift=prev['zeros'],
+                                  relu_aux=acts[k - 1])
+            d = ops.conv_gemm(g, pitch_layers[0]['pack'], None, transpose=True)
+            dmel = dmel + ops.transpose(d)
+        total = terms[0] + terms[2] + terms[3] + terms[4] + cfg['ecw'] * terms[5] + cfg['pcw'] * terms[6]
+        ctx.save_for_backward(dmel, d_spk, d_pm)
+        ctx.mark_non_differentiable(terms)
+        return total, terms
+
+    @staticmethod
+    def backward(ctx, g_total, _g_terms):
+        dmel, d_spk, d_pm = ctx.saved_tensors
+        return (dmel * g_total, None if d_spk is None else d_spk * g_total, None if d_pm is None else d_pm * g_total,
+                None, None, None, None, None, None)
+
+
+class DaftExprtLoss(nn.Module):
+    def __init__(self, device, hparams):
+        super().__init__()
+        self.device = device
+        self.nb_channels = hparams.n_mel_channels
+        self.warmup_steps = getattr(hparams, 'warmup_steps', 10000)
+        self.adv_max_weight = getattr(hparams, 'adv_max_weight', 1e-2)
+        self.post_mult_weight = getattr(hparams, 'post_mult_weight', 1e-3)
+        self.mel_spec_weight = getattr(hparams, 'mel_spec_weight', 1.0)
+        self.energy_consistency_weight = getattr(hparams, 'energy_consistency_weight', 0.0)
+        self.pitch_consistency_weight = getattr(hparams, 'pitch_consistency_weight', 0.0)
+        self.pitch_layers = None
+        pp_path = getattr(hparams, 'pitch_predictor_path', '')
+        if self.pitch_consistency_weight > 0 and pp_path:
+            state = torch.load(pp_path, map_location='cpu', weights_only=True)
+            self.load_pitch_predictor(state)
+
+    def load_pitch_predictor(self, state_dict):
+        """Frozen predictor from an in-memory state dict (same keys as layers/pitch_predictor.py)."""
+        self.pitch_layers = fold_pitch_predictor(state_dict, self.device)
+
+    def update_adversarial_weight(self, iteration):
+        """loss.py:52-55"""
+        weight_iter = iteration * self.warmup_steps ** -1.5 * self.adv_max_weight / self.warmup_steps ** -0.5
+        return min(self.adv_max_weight, weight_iter)
+
+    def forward(self, outputs, targets, iteration):
+        if len(targets) == 8:
+            _, _, _, mel_targets, output_lengths, speaker_ids, _frames_energy, frames_pitch = targets
+        else:
+            _, _, _, mel_targets, output_lengths, speaker_ids = targets
+            frames_pitch = None
+        speaker_preds, film_params, _, decoder_preds, _ = outputs
+        post_multipliers = film_params[0]
+        mel_preds, output_lengths = decoder_preds
+        if not mel_preds.is_cuda:
+            raise RuntimeError('DaftExprtLoss (MI355X build) runs on the GPU only; there is no CPU path')
+        lens = output_lengths if isinstance(output_lengths, Lengths) else Lengths(output_lengths)
+        pm = post_multipliers if (self.post_mult_weight != 0.0 and torch.is_tensor(post_multipliers)) else None
+        cfg = {'spk_weight': self.update_adversarial_weight(iteration), 'pmw': self.post_mult_weight, 'msw': self.mel_spec_weight,
+               'ecw': self.energy_consistency_weight, 'pcw': self.pitch_consistency_weight if self.pitch_layers is not None else 0.0}
+        total, terms = _LossFn.apply(mel_preds, speaker_preds, pm, mel_targets, speaker_ids, frames_pitch, lens, cfg, self.pitch_layers)
+        t = terms.tolist()                                                  # the only host sync of the loss
+        individual = {'speaker_loss': t[0], 'speaker_ce_raw': t[1], 'post_mult_loss': t[2], 'mel_spec_l1_loss': t[3],
+                      'mel_spec_l2_loss': t[4], 'energy_consistency_loss': t[5], 'pitch_consistency_loss': t[6]}
+        return total, individual

@@ -69,7 +69,7 @@ class PackedWeight:
         dims = (ctypes.c_int * 4)()
         lib().dx_pack_dims(self.cout, self.cin, bf16, ctypes.cast(dims, ctypes.c_void_p))
         dt = torch.bfloat16 if bf16 else torch.float32
-        if self.fwd is None or self.fwd.dtype != dt:
+        if self.fwd is None or self.fwd.dtype != dt or self.fwd.device != w.device:
             self.fwd = torch.empty(self.taps * int(dims[0]) * int(dims[1]), dtype=dt, device=w.device)
             self.bwd = torch.empty(self.taps * int(dims[2]) * int(dims[3]), dtype=dt, device=w.device)
         lib().dx_pack_weights(_p(w.detach()), _p(self.fwd), _p(self.bwd), self.cout, self.cin, self.taps, bf16, _stream())
