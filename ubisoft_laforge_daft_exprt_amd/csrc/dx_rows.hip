@@ -334,15 +334,34 @@ __global__ __launch_bounds__(256) void scalar_conv_wgrad_kernel(const float* __r
   if (x1) atomicAdd(&db1[c], ab);
 }
 
-// pooled[b,c] += sum_{n in chunk} x[b,n,c] / len_b
-__global__ __launch_bounds__(128) void mean_pool_kernel(const float* __restrict__ x, const int* __restrict__ lens, float* __restrict__ out,
-                                                        int B, int N, int C, int rows_per_block) {
-  const int b = blockIdx.y, c = threadIdx.x;
-  const int n_begin = blockIdx.x * rows_per_block, n_end = min(N, n_begin + rows_per_block);
-  for (int cc = c; cc < C; cc += 128) {
-    float s = 0.f;
-    for (int n = n_begin; n < n_end; ++n) s += x[((size_t)b * N + n) * C + cc];
-    atomicAdd(&out[(size_t)b * C + cc], s / (float)lens[b]);
+// pooled[b,c] = sum_n x[b,n,c] / len_b.  One block per utterance, fixed summation order (bitwise reproducible).
+__global__ __launch_bounds__(256) void mean_pool_kernel(const float* __restrict__ x, const int* __restrict__ lens, float* __restrict__ out,
+                                                        int B, int N, int C) {
+  __shared__ float part[256];
+  const int b = blockIdx.x;
+  const int lanes = min(C, 256);                 // C == 128: two row-halves per channel
+  const int groups = 256 / lanes;
+  const int g = threadIdx.x / lanes;
+  for (int c0 = 0; c0 < C; c0 += lanes) {
+    const int c = c0 + threadIdx.x % lanes;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (g < groups && c < C) {
+      const float* xb = x + (size_t)b * N * C + c;
+      int n = g;
+      for (; n + 3 * groups < N; n += 4 * groups) {
+        s0 += xb[(size_t)n * C]; s1 += xb[(size_t)(n + groups) * C];
+        s2 += xb[(size_t)(n + 2 * groups) * C]; s3 += xb[(size_t)(n + 3 * groups) * C];
+      }
+      for (; n < N; n += groups) s0 += xb[(size_t)n * C];
+    }
+    __syncthreads();
+    part[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && c < C) {
+      float s = 0.f;
+      for (int k = 0; k < groups; ++k) s += part[k * lanes + threadIdx.x];
+      out[(size_t)b * C + c] = s / (float)lens[b];
+    }
   }
 }
 
@@ -527,11 +546,9 @@ int dx_scalar_conv_wgrad(const float* dout, int ldd, const float* rowscale, cons
   return DX_OK;
 }
 
-// out (caller-zeroed) [B][C]
 int dx_mean_pool(const float* x, const int* lens, float* out, int B, int N, int C, void* stream) {
   DX_REQUIRE(x && lens && out && B > 0 && N > 0 && C > 0, "dx_mean_pool: bad arguments");
-  const int rpb = 32;
-  hipLaunchKernelGGL(mean_pool_kernel, dim3(dx_cdiv(N, rpb), B), dim3(128), 0, (hipStream_t)stream, x, lens, out, B, N, C, rpb);
+  hipLaunchKernelGGL(mean_pool_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, lens, out, B, N, C);
   DX_LAUNCH_CHECK("dx_mean_pool");
   return DX_OK;
 }

@@ -1,0 +1,86 @@
+"""Data-parallel gradient exchange: bucketed all-reduce over RCCL (xGMI), overlapped with backward.
+
+The reference wraps the model in ``torch.nn.parallel.DistributedDataParallel`` (src/daft_exprt/train.py:272); the only
+exchange step of the path is the gradient all-reduce of 14.4 M fp32 values (57.5 MB) per step.
+Utterances are independent units, so the forward/backward itself needs no collective.
+
+Design for one process per GPU on an 8-GPU xGMI mesh:
+  * parameters are packed, in reverse registration order (~ the order autograd finishes them), into a few flat fp32
+    buckets; ``param.grad`` is a VIEW into its bucket, so autograd accumulates straight into the communication buffer
+  * a post-accumulate hook counts ready parameters; when a bucket is complete its all-reduce is issued asynchronously
+    (``backend='nccl'`` is RCCL on ROCm) while the rest of backward keeps running on the compute stream
+  * ``finish()`` waits for the outstanding collectives; averaging uses ReduceOp.AVG where the backend has it
+Few, large messages: with 7 point-to-point links per GPU the all-reduce is per-link bound, so 2-4 buckets of 16-32 MB
+amortise latency without delaying the first launch until the end of backward.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class GradientReducer:
+    def __init__(self, module: torch.nn.Module, bucket_mb: float = 16.0, process_group=None):
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        params = [p for p in module.parameters() if p.requires_grad]
+        params.reverse()
+        cap = int(bucket_mb * 1024 * 1024 / 4)
+        self.buckets = []
+        cur, cur_n = [], 0
+        for p in params:
+            if cur and cur_n + p.numel() > cap:
+                self.buckets.append(cur)
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            self.buckets.append(cur)
+        self.flat, self.bucket_of = [], {}
+        for bi, bucket in enumerate(self.buckets):
+            n = sum(p.numel() for p in bucket)
+            flat = torch.zeros(n, dtype=bucket[0].dtype, device=bucket[0].device)
+            off = 0
+            for p in bucket:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+                self.bucket_of[p] = bi
+            self.flat.append(flat)
+        self.pending = [len(b) for b in self.buckets]
+        self.works = []
+        self.hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+        self._avg = None
+
+    def _reduce_op(self):
+        if self._avg is None:
+            backend = dist.get_backend(self.group)
+            self._avg = dist.ReduceOp.AVG if backend == 'nccl' else dist.ReduceOp.SUM
+        return self._avg
+
+    def _on_grad(self, p):
+        bi = self.bucket_of[p]
+        self.pending[bi] -= 1
+        if self.pending[bi] == 0 and self.world > 1:
+            op = self._reduce_op()
+            work = dist.all_reduce(self.flat[bi], op=op, group=self.group, async_op=True)
+            self.works.append((work, bi, op))
+
+    def zero_grad(self):
+        """Keeps the grad views alive (set_to_none would detach them from the buckets)."""
+        for flat in self.flat:
+            flat.zero_()
+        self.pending = [len(b) for b in self.buckets]
+
+    def finish(self):
+        """Call after backward: waits for the collectives; gradients are then averaged over ranks."""
+        for work, bi, op in self.works:
+            work.wait()
+            if op == dist.ReduceOp.SUM and self.world > 1:
+                self.flat[bi].div_(self.world)
+        self.works = []
+        self.pending = [len(b) for b in self.buckets]
+
+    def remove(self):
+        for h in self.hooks:
+            h.remove()

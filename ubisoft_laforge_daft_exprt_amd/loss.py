@@ -155,7 +155,57 @@ class DaftExprtLoss(nn.Module):
         cfg = {'spk_weight': self.update_adversarial_weight(iteration), 'pmw': self.post_mult_weight, 'msw': self.mel_spec_weight,
                'ecw': self.energy_consistency_weight, 'pcw': self.pitch_consistency_weight if self.pitch_layers is not None else 0.0}
         total, terms = _LossFn.apply(mel_preds, speaker_preds, pm, mel_targets, speaker_ids, frames_pitch, lens, cfg, self.pitch_layers)
-        t = terms.tolist()                                                  # the only host sync of the loss
-        individual = {'speaker_loss': t[0], 'speaker_ce_raw': t[1], 'post_mult_loss': t[2], 'mel_spec_l1_loss': t[3],
-                      'mel_spec_l2_loss': t[4], 'energy_consistency_loss': t[5], 'pitch_consistency_loss': t[6]}
-        return total, individual
+        return total, LossTerms(terms)
+
+
+class LossTerms(dict):
+    """The reference's ``individual_loss`` dict of 7 floats (loss.py:149-157).  The values live in one device tensor and are
+    fetched with a single host transfer on FIRST ACCESS, so a training loop that only logs every n-th step never stalls
+    the stream between forward and backward (the reference does seven ``.item()`` syncs per step)."""
+
+    KEYS = ('speaker_loss', 'speaker_ce_raw', 'post_mult_loss', 'mel_spec_l1_loss', 'mel_spec_l2_loss',
+            'energy_consistency_loss', 'pitch_consistency_loss')
+
+    def __init__(self, device_terms):
+        super().__init__()
+        self._device_terms = device_terms
+
+    def _fetch(self):
+        if self._device_terms is not None:
+            values = self._device_terms.tolist()
+            self._device_terms = None
+            super().update(zip(self.KEYS, values))
+
+    def __getitem__(self, k):
+        self._fetch()
+        return super().__getitem__(k)
+
+    def __iter__(self):
+        self._fetch()
+        return super().__iter__()
+
+    def __len__(self):
+        return len(self.KEYS)
+
+    def __contains__(self, k):
+        return k in self.KEYS
+
+    def keys(self):
+        self._fetch()
+        return super().keys()
+
+    def items(self):
+        self._fetch()
+        return super().items()
+
+    def values(self):
+        self._fetch()
+        return super().values()
+
+    def get(self, k, default=None):
+        self._fetch()
+        return super().get(k, default)
+
+    def __repr__(self):
+        self._fetch()
+        return super().__repr__()

@@ -12,6 +12,20 @@ import torch
 from ._lib import lib
 
 _PRECISION = {'bf16': 0}
+_PACK_EPOCH = [0]
+_LAUNCH_LOG = [None]
+
+
+def invalidate_packs() -> None:
+    """Forces every PackedWeight to re-pack on next use (what an optimiser step does by bumping parameter versions)."""
+    _PACK_EPOCH[0] += 1
+
+
+def record_launches(enable: bool):
+    """bench.py: collect (kind, rows, N, Cin, Cout, taps) of every GEMM launch to price algorithmic FLOPs."""
+    log = _LAUNCH_LOG[0]
+    _LAUNCH_LOG[0] = [] if enable else None
+    return log
 
 
 def set_precision(name: str) -> None:
@@ -62,7 +76,7 @@ class PackedWeight:
 
     def refresh(self):
         w = self.weight
-        key = (w._version, w.data_ptr(), _PRECISION['bf16'])
+        key = (w._version, w.data_ptr(), _PRECISION['bf16'], _PACK_EPOCH[0])
         if key == self._key:
             return self
         bf16 = _PRECISION['bf16']
@@ -94,6 +108,8 @@ def conv_gemm(x, pack: PackedWeight, bias=None, *, transpose=False, relu=False, 
     if out is None:
         out = torch.empty(*x.shape[:-1], cout, dtype=torch.float32, device=x.device)
     ldy = _rows(out)
+    if _LAUNCH_LOG[0] is not None:
+        _LAUNCH_LOG[0].append(('conv', B_ * N_, N_, cin, cout, pack.taps))
     lib().dx_conv_gemm(_p(x), ldx, _p(pack.bwd if transpose else pack.fwd), _p(bias), _p(out), ldy, B_, N_, cin, cout, pack.taps,
                        pack.bf16, int(relu), _p(post_scale), _p(post_shift), _p(relu_aux),
                        0 if relu_aux is None else _rows(relu_aux), int(accumulate), _p(lens), int(mask_rows), float(out_scale), _stream())
@@ -104,6 +120,8 @@ def conv_wgrad(dy, x, pack: PackedWeight):
     """Gradient w.r.t. the (Cout, Cin[, taps]) parameter, in the parameter's own layout."""
     B_, N_ = (1, x.shape[0]) if x.dim() == 2 else (x.shape[0], x.shape[1])
     g = torch.zeros(pack.taps * pack.cout * pack.cin, dtype=torch.float32, device=x.device)
+    if _LAUNCH_LOG[0] is not None:
+        _LAUNCH_LOG[0].append(('wgrad', B_ * N_, N_, pack.cin, pack.cout, pack.taps))
     lib().dx_conv_wgrad(_p(dy), _rows(dy), _p(x), _rows(x), _p(g), B_, N_, pack.cin, pack.cout, pack.taps, _stream())
     if pack.taps == 1:
         return g.view(pack.weight.shape)
