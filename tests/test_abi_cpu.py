@@ -1,0 +1,103 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol the header declares, and the
+Python module owns the reference's state-dict layout.  No compute call is made (there is no GPU here)."""
+import ctypes
+import os
+
+import pytest
+import torch
+
+from tests import helpers
+
+
+def test_library_exports_every_declared_symbol():
+    from ubisoft_laforge_daft_exprt_amd import _lib
+    protos = _lib.parse_header()
+    assert len(protos) >= 36
+    assert os.path.exists(_lib.LIB_PATH), 'build it: python -m ubisoft_laforge_daft_exprt_amd.build'
+    dll = ctypes.CDLL(_lib.LIB_PATH)
+    for name in protos:
+        assert hasattr(dll, name), name
+    lib = _lib.lib()
+    assert lib.dx_version() == 1
+
+
+def test_argument_validation_without_gpu():
+    from ubisoft_laforge_daft_exprt_amd._lib import lib, DxError
+    with pytest.raises(DxError, match='taps'):
+        lib().dx_pack_weights(1, 1, None, 8, 8, 2, 0, None)           # argument checks run before any launch
+    with pytest.raises(DxError, match='null'):
+        lib().dx_conv_gemm(None, 0, None, None, None, 0, 1, 1, 4, 4, 1, 0, 0, None, None, None, 0, 0, None, 0, 1.0, None)
+
+
+def test_state_dict_layout_matches_reference_manifest():
+    import ubisoft_laforge_daft_exprt_amd as pkg
+    man = helpers.manifest()
+    model = pkg.DaftExprt(helpers.golden_hparams())
+    sd = model.state_dict()
+    assert list(sorted(sd)) == list(sorted(man['model']))
+    for k, shape in man['model'].items():
+        assert list(sd[k].shape) == shape, k
+        assert sd[k].dtype == torch.float32
+    assert sum(p.numel() for p in model.parameters()) == man['n_parameters']
+    assert len(list(model.buffers())) == 0
+    model.load_state_dict(helpers.golden_state_dict(), strict=True)
+    # DDP-style 'module.' prefixed checkpoints are stripped by the reference's consumers (fine_tune.py:40); same keys here
+    nopm = pkg.DaftExprt(helpers.golden_hparams(post_mult_weight=0.0))
+    assert 'style_adapter.post_multipliers' not in nopm.state_dict()
+    assert nopm.style_adapter.post_multipliers == 1.0
+
+
+def test_no_cpu_fallback_and_reference_errors():
+    import ubisoft_laforge_daft_exprt_amd as pkg
+    model = pkg.DaftExprt(helpers.golden_hparams())
+    inputs, _ = helpers.case_inputs(helpers.load_case('train_single'))
+    with pytest.raises(ValueError):
+        model(inputs[:11])
+    with pytest.raises(RuntimeError, match='GPU'):
+        model(inputs)
+    with pytest.raises(ValueError):
+        model.parse_batch('cpu', inputs)
+
+
+def test_duration_rounding_is_bit_exact_against_reference_kats():
+    import json
+    from ubisoft_laforge_daft_exprt_amd.durations import duration_to_integer, get_int_durations
+    with open(os.path.join(helpers.GOLDEN, 'duration_kats.json')) as f:
+        kats = json.load(f)
+    hp = helpers.golden_hparams()
+    for kat in kats['duration_to_integer']:
+        hpk = hp.clone(centered=True) if kat.get('centered') else hp
+        try:
+            got = duration_to_integer([list(s) for s in kat['spans']], hpk)
+        except (IndexError, ValueError) as exc:
+            got = type(exc).__name__
+        assert got == kat['expected'], kat
+    g = kats['get_int_durations']
+    f_out, i_out = get_int_durations(torch.tensor(g['input'], dtype=torch.float32), hp)
+    assert i_out.tolist() == g['int_out'] and f_out.tolist() == g['float_out']
+
+
+def test_duration_rounding_matches_oracle_on_random_rows():
+    from oracle import daft_exprt_oracle as oracle
+    from ubisoft_laforge_daft_exprt_amd.durations import get_int_durations
+    hp = helpers.golden_hparams()
+    g = torch.Generator().manual_seed(0)
+    for _ in range(20):
+        rows = (0.2 * torch.rand(3, 40, generator=g)).float()
+        rows[:, 0] = 0.1
+        rows = rows * (torch.rand(3, 40, generator=g) > 0.2)
+        rows[:, 0] = 0.1
+        a = get_int_durations(rows.clone(), hp)
+        b = oracle.get_int_durations(rows.clone(), hp)
+        assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
+
+
+def test_synthetic_batch_contract():
+    from ubisoft_laforge_daft_exprt_amd.synth import CONFIGS, synthetic_batch
+    batch = synthetic_batch(**CONFIGS['C1'])
+    assert len(batch) == 14
+    symbols, dur_f, dur_i, s_e, s_p, in_l, f_e, f_p, mel, out_l, spk, _, _, emb = batch
+    assert torch.equal(dur_i.sum(1), out_l) and in_l.tolist() == sorted(in_l.tolist(), reverse=True)
+    assert mel.shape == (4, 80, int(out_l.max())) and emb.shape == (4, 192)
+    for b in range(4):
+        assert (symbols[b, int(in_l[b]):] == 0).all() and (mel[b, :, int(out_l[b]):] == 0).all()
