@@ -37,19 +37,25 @@ int dx_pack_dims(int Cout, int Cin, int bf16, int* dims);
 /* W: checkpoint layout (Cout, Cin, taps) fp32 -> fwd pack [taps][CoutP][CinP], bwd pack (input-gradient conv) or NULL */
 int dx_pack_weights(const float* W, void* fwd, void* bwd, int Cout, int Cin, int taps, int bf16, void* stream);
 /* Y[b,n,:] = out_scale * mask( relu_aux>0 ? . : 0 )( post_scale * relu?( bias + conv(X) ) + post_shift )  (+= if accumulate)
- * taps 1 (Linear) or 3 (zero 'same' padding inside each batch row).  NULL disables an epilogue stage. */
-int dx_conv_gemm(const float* X, int ldx, const void* Wp, const float* bias, float* Y, int ldy,
+ * taps 1 (Linear) or 3 (zero 'same' padding inside each batch row).  NULL disables an epilogue stage.
+ * skip_halo >= 0: 128-token tiles that start at or beyond lens[b] + skip_halo are padding nobody reads: zero-filled, not computed
+ * (the reference computes the whole padded grid; rows within the halo of a k=3 stack are still computed). */
+int dx_conv_gemm(const void* X, int ldx, const void* Wp, const float* bias, void* Y, int ldy,
                  int B, int N, int Cin, int Cout, int taps, int bf16,
                  int relu, const float* post_scale, const float* post_shift,
-                 const float* relu_aux, int ld_aux, int accumulate,
-                 const int* lens, int mask_rows, float out_scale, void* stream);
+                 const void* relu_aux, int ld_aux, int accumulate,
+                 const int* lens, int mask_rows, float out_scale, int skip_halo,
+                 int x_bf16, int y_bf16, int aux_bf16, void* stream);
+/* x_bf16 / y_bf16 / aux_bf16 = 1: that tensor is stored as bf16 (bf16 operand mode only; ld* count elements).  Used for the
+ * 1024-wide hidden activations of the conv feed-forward and the prenet, whose HBM traffic otherwise bounds the step. */
 /* G[taps][Cout][Cin] (fp32, caller-zeroed) += dY^T * shifted X   (autograd of the conv w.r.t. its weight) */
-int dx_conv_wgrad(const float* dY, int ldy, const float* X, int ldx, float* G,
-                  int B, int N, int Cin, int Cout, int taps, void* stream);
+int dx_conv_wgrad(const void* dY, int ldy, const void* X, int ldx, float* G,
+                  int B, int N, int Cin, int Cout, int taps, const int* lens, int skip_halo,
+                  int bf16, int dy_bf16, int x_bf16, void* stream);
 /* grad (Cout, Cin, taps) (+)= G[taps][Cout][Cin] */
 int dx_unpack_wgrad(const float* G, float* grad, int Cout, int Cin, int taps, int accumulate, void* stream);
 /* out[c] += sum_rows X[row][c]   (bias gradients) */
-int dx_colsum(const float* X, int ldx, float* out, long rows, int C, void* stream);
+int dx_colsum(const void* X, int ldx, float* out, long rows, int C, int x_bf16, void* stream);
 
 /* ---- multi-head attention: model.py:165-186 (nn.MultiheadAttention slow path), called from :255 ------------------- */
 int dx_attention_fwd(const float* qkv, int ld, const int* lens, float* ctx, int ldc, float* lse,

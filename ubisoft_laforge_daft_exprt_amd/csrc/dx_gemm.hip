@@ -42,6 +42,8 @@ struct ConvGemmArgs {
   int accumulate;
   const int* lens; int mask_rows;
   float out_scale;
+  int skip_halo;   // >= 0: token tiles starting at or beyond min(len_b + skip_halo, N) are not computed (zero-filled)
+  int x_bf16, y_bf16, aux_bf16;   // storage type of X / Y / relu_aux (bf16 operand mode only); ld* are in elements
 };
 
 template <typename T> struct Mma;
@@ -84,6 +86,27 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
   const T* Wp = reinterpret_cast<const T*>(a.Wp);
   const float* Xb = a.X + (size_t)b * a.N * a.ldx;
 
+  if (a.skip_halo >= 0 && n0 >= a.lens[b] + a.skip_halo) {
+    // whole tile is padding beyond the halo: nothing downstream reads it with a non-zero weight; keep it defined
+    if (!a.accumulate) {
+      for (int u = tid; u < TILE * 32; u += 256) {
+        const int row = u >> 5, q = u & 31;
+        const int n = n0 + row, co = co0 + q * 4;
+        if (n < a.N && co < a.Cout) {
+          if (a.y_bf16) {
+            __bf16* dst = reinterpret_cast<__bf16*>(a.Y) + ((size_t)b * a.N + n) * a.ldy + co;
+            *reinterpret_cast<uint2*>(dst) = make_uint2(0u, 0u);       // bf16 outputs always have Cout % 4 == 0
+          } else {
+            float* dst = a.Y + ((size_t)b * a.N + n) * a.ldy + co;
+            if (co + 3 < a.Cout) *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+            else for (int e = 0; co + e < a.Cout; ++e) dst[e] = 0.f;
+          }
+        }
+      }
+    }
+    return;
+  }
+
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -108,6 +131,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
         const int n = n0 + row - PAD, ci = ci0 + q * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n >= 0 && n < a.N && ci < a.Cin) v = *reinterpret_cast<const float4*>(Xb + (size_t)n * a.ldx + ci);
+        *reinterpret_cast<float4*>(Xs + row * ROWB + q * 16) = v;
+      }
+    } else if (a.x_bf16) {
+      const __bf16* Xh = reinterpret_cast<const __bf16*>(a.X) + (size_t)b * a.N * a.ldx;
+      for (int u = tid; u < XROWS * 8; u += 256) {
+        const int row = u >> 3, q = u & 7;
+        const int n = n0 + row - PAD, ci = ci0 + q * 8;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n >= 0 && n < a.N && ci < a.Cin) v = *reinterpret_cast<const float4*>(Xh + (size_t)n * a.ldx + ci);
         *reinterpret_cast<float4*>(Xs + row * ROWB + q * 16) = v;
       }
     } else {
@@ -168,11 +200,23 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
         v[e] = t * a.out_scale;
       }
       if (a.relu_aux) {
+        if (a.aux_bf16) {
+          const bf16x4 av = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.relu_aux) + row * a.ld_aux + co);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (co + e < a.Cout && !(a.relu_aux[row * a.ld_aux + co + e] > 0.f)) v[e] = 0.f;
+          for (int e = 0; e < 4; ++e)
+            if (!((float)av[e] > 0.f)) v[e] = 0.f;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < a.Cout && !(a.relu_aux[row * a.ld_aux + co + e] > 0.f)) v[e] = 0.f;
+        }
       }
       if (a.mask_rows && n >= len_b) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+      if (a.y_bf16) {
+        __bf16* dsth = reinterpret_cast<__bf16*>(a.Y) + row * a.ldy + co;
+        *reinterpret_cast<uint2*>(dsth) = pack_bf16x4(make_float4(v[0], v[1], v[2], v[3]));
+        continue;
+      }
       float* dst = a.Y + row * a.ldy + co;
       if (full) {
         float4 o = make_float4(v[0], v[1], v[2], v[3]);
@@ -201,6 +245,7 @@ struct WgradArgs {
   const float* X; int ldx;
   float* G;
   int B, N, Cin, Cout, ksplit;
+  const int* lens; int skip_halo;   // chunks starting at or beyond len_b + skip_halo carry a zero dY: skipped
 };
 
 constexpr int WG_BK = 32;     // tokens per K chunk
@@ -221,9 +266,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 
   const int chunks_per_row = (a.N + WG_BK - 1) / WG_BK;
   const int total = a.B * chunks_per_row;
-  const int per = (total + a.ksplit - 1) / a.ksplit;
-  const int c_begin = blockIdx.z * per;
-  const int c_end = min(total, c_begin + per);
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -231,9 +273,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int c = c_begin; c < c_end; ++c) {
+  for (int c = blockIdx.z; c < total; c += a.ksplit) {   // interleaved split: every slice sees a mix of utterance lengths
     const int b = c / chunks_per_row;
     const int nc = (c - b * chunks_per_row) * WG_BK;
+    if (a.skip_halo >= 0 && nc >= a.lens[b] + a.skip_halo) continue;
     const float* dYb = a.dY + (size_t)b * a.N * a.ldy;
     const float* Xb = a.X + (size_t)b * a.N * a.ldx;
     __syncthreads();
@@ -287,6 +330,116 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// weight gradient, bf16 MFMA operands (fp32 accumulate).  dY and X tiles are staged UNTRANSPOSED as bf16
+// [token][channel] (288-B rows) and every lane gathers its 8 K(=token)-consecutive values of one channel with two
+// ds_read_b64_tr_b16 (hardware transposed read: a 16-lane group reads a 4-token x 16-channel block and each lane
+// receives one channel column) -- no transposing store pass, no shuffles.
+// ------------------------------------------------------------------------------------------------
+constexpr int WB_BK = 64;      // tokens per K chunk
+constexpr int WB_LD = 144;     // LDS row stride in bf16 elements (288 B)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct WgradBf16Args {
+  const void* dY; int ldy; int dy_bf16;
+  const void* X; int ldx; int x_bf16;
+  float* G;
+  int B, N, Cin, Cout, ksplit;
+  const int* lens; int skip_halo;
+};
+
+__device__ __forceinline__ bf16x8 tr_fragment(const __bf16* tile, int row0, int col0, int lane) {
+  // rows row0 + 8g + [0,8), columns col0 + [0,16): lane (r = lane & 15, g = lane >> 4) gets column r, rows 8g..8g+7
+  const int li = lane & 15, g = lane >> 4, q = li >> 2, p = li & 3;
+  const __bf16* a0 = tile + (row0 + 8 * g + q) * WB_LD + col0 + 4 * p;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * WB_LD));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// stage `rows` token rows (first = n_first, may be < 0 or >= N -> zeros) x 128 channels starting at c0 as bf16
+__device__ __forceinline__ void stage_bf16(__bf16* dst, const void* src, int ld, int is_bf16, size_t batch_off, int n_first, int rows,
+                                           int c0, int C, int N, int tid) {
+  if (is_bf16) {
+    const __bf16* base = reinterpret_cast<const __bf16*>(src) + batch_off;
+    for (int u = tid; u < rows * 16; u += 256) {
+      const int row = u >> 4, q = u & 15;
+      const int n = n_first + row, c = c0 + q * 8;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n >= 0 && n < N && c < C) v = *reinterpret_cast<const float4*>(base + (size_t)n * ld + c);
+      *reinterpret_cast<float4*>(dst + row * WB_LD + q * 8) = v;
+    }
+  } else {
+    const float* base = reinterpret_cast<const float*>(src) + batch_off;
+    for (int u = tid; u < rows * 32; u += 256) {
+      const int row = u >> 5, q = u & 31;
+      const int n = n_first + row, c = c0 + q * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n >= 0 && n < N && c < C) v = *reinterpret_cast<const float4*>(base + (size_t)n * ld + c);
+      *reinterpret_cast<uint2*>(dst + row * WB_LD + q * 4) = pack_bf16x4(v);
+    }
+  }
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBf16Args a) {
+  constexpr int PAD = (TAPS - 1) / 2;
+  __shared__ __attribute__((aligned(16))) __bf16 Ds[WB_BK * WB_LD];
+  __shared__ __attribute__((aligned(16))) __bf16 Xs[(WB_BK + 8) * WB_LD];   // +2 halo rows, padded so every tr read stays in bounds
+  const int ci_tiles = (a.Cin + TILE - 1) / TILE;
+  const int co0 = (blockIdx.x / ci_tiles) * TILE;
+  const int ci0 = (blockIdx.x % ci_tiles) * TILE;
+  const int tap = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave >> 1, wt = wave & 1;
+  const int r = lane & 15, g = lane >> 4;
+  const int chunks_per_row = (a.N + WB_BK - 1) / WB_BK;
+  const int total = a.B * chunks_per_row;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int u = tid; u < 8 * WB_LD; u += 256) Xs[(WB_BK) * WB_LD + u] = (__bf16)0.f;   // rows 64..71 (halo rows 64, 65 rewritten per chunk)
+
+  for (int c = blockIdx.z; c < total; c += a.ksplit) {
+    const int b = c / chunks_per_row;
+    const int nc = (c - b * chunks_per_row) * WB_BK;
+    if (a.skip_halo >= 0 && nc >= a.lens[b] + a.skip_halo) continue;
+    __syncthreads();
+    stage_bf16(Ds, a.dY, a.ldy, a.dy_bf16, (size_t)b * a.N * a.ldy, nc, WB_BK, co0, a.Cout, a.N, tid);
+    stage_bf16(Xs, a.X, a.ldx, a.x_bf16, (size_t)b * a.N * a.ldx, nc - PAD, WB_BK + TAPS - 1, ci0, a.Cin, a.N, tid);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < WB_BK / 32; ++ks) {
+      bf16x8 df[4], xf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) df[i] = tr_fragment(Ds, ks * 32, wc * 64 + i * 16, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xf[j] = tr_fragment(Xs, ks * 32 + tap, wt * 64 + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ci = ci0 + wt * 64 + j * 16 + r;
+      if (ci >= a.Cin) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = co0 + wc * 64 + i * 16 + g * 4 + e;
+        if (co < a.Cout && acc[i][j][e] != 0.f) atomicAdd(&a.G[((size_t)tap * a.Cout + co) * a.Cin + ci], acc[i][j][e]);
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // packing: checkpoint layout (Cout, Cin, TAPS) fp32 -> fwd [TAPS][CoutP][CinP], bwd [TAPS][CinPo][CoutPi]
 // (bwd = transposed channels, flipped taps: the input-gradient conv).
 // ------------------------------------------------------------------------------------------------
@@ -324,8 +477,9 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ G, float* __restri
   }
 }
 
-// column sums: out[c] += sum_rows X[row][c]   (bias gradients)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int ldx, float* __restrict__ out,
+// column sums: out[c] += sum_rows X[row][c]   (bias gradients); X fp32 or bf16
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int ldx, float* __restrict__ out,
                                                      long rows, int C, int rows_per_block) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
@@ -334,13 +488,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   long rr = r0;
   for (; rr + 3 < r1; rr += 4) {
-    s0 += X[(size_t)rr * ldx + c];
-    s1 += X[(size_t)(rr + 1) * ldx + c];
-    s2 += X[(size_t)(rr + 2) * ldx + c];
-    s3 += X[(size_t)(rr + 3) * ldx + c];
+    s0 += (float)X[(size_t)rr * ldx + c];
+    s1 += (float)X[(size_t)(rr + 1) * ldx + c];
+    s2 += (float)X[(size_t)(rr + 2) * ldx + c];
+    s3 += (float)X[(size_t)(rr + 3) * ldx + c];
   }
-  for (; rr < r1; ++rr) s0 += X[(size_t)rr * ldx + c];
-  atomicAdd(&out[c], (s0 + s1) + (s2 + s3));
+  for (; rr < r1; ++rr) s0 += (float)X[(size_t)rr * ldx + c];
+  const float t = (s0 + s1) + (s2 + s3);
+  if (t != 0.f) atomicAdd(&out[c], t);
 }
 
 template <typename T, int TAPS>
@@ -388,12 +543,19 @@ int dx_pack_weights(const float* W, void* fwd, void* bwd, int Cout, int Cin, int
 }
 
 // Y = epilogue(conv(X, Wp) + bias).  See ConvGemmArgs for the epilogue switches.
-int dx_conv_gemm(const float* X, int ldx, const void* Wp, const float* bias, float* Y, int ldy,
+int dx_conv_gemm(const void* Xv, int ldx, const void* Wp, const float* bias, void* Yv, int ldy,
                  int B, int N, int Cin, int Cout, int taps, int bf16,
                  int relu, const float* post_scale, const float* post_shift,
-                 const float* relu_aux, int ld_aux, int accumulate,
-                 const int* lens, int mask_rows, float out_scale, void* stream) {
+                 const void* relu_auxv, int ld_aux, int accumulate,
+                 const int* lens, int mask_rows, float out_scale, int skip_halo,
+                 int x_bf16, int y_bf16, int aux_bf16, void* stream) {
+  const float* X = (const float*)Xv; float* Y = (float*)Yv; const float* relu_aux = (const float*)relu_auxv;
   DX_REQUIRE(X && Wp && Y, "dx_conv_gemm: null pointer");
+  DX_REQUIRE(bf16 || !(x_bf16 || y_bf16 || aux_bf16), "dx_conv_gemm: bf16 storage needs bf16 operand mode");
+  DX_REQUIRE(!x_bf16 || ((Cin % 8) == 0 && (ldx % 8) == 0), "dx_conv_gemm: bf16 input needs Cin, ldx multiples of 8");
+  DX_REQUIRE(!y_bf16 || ((Cout % 4) == 0 && (ldy % 4) == 0 && !accumulate), "dx_conv_gemm: bf16 output needs Cout, ldy multiples of 4 and no accumulate");
+  DX_REQUIRE(!aux_bf16 || ((Cout % 4) == 0 && (ld_aux % 4) == 0), "dx_conv_gemm: bf16 relu_aux needs Cout, ld_aux multiples of 4");
+  DX_REQUIRE(skip_halo < 0 || lens, "dx_conv_gemm: skip_halo needs lens");
   DX_REQUIRE(B > 0 && N > 0 && Cin > 0 && Cout > 0, "dx_conv_gemm: bad dims B=%d N=%d Cin=%d Cout=%d", B, N, Cin, Cout);
   DX_REQUIRE(taps == 1 || taps == 3, "dx_conv_gemm: taps must be 1 or 3 (got %d)", taps);
   DX_REQUIRE((Cin % 4) == 0 && (ldx % 4) == 0 && ldx >= Cin, "dx_conv_gemm: Cin (%d) and ldx (%d) must be multiples of 4, ldx >= Cin", Cin, ldx);
@@ -405,7 +567,7 @@ int dx_conv_gemm(const float* X, int ldx, const void* Wp, const float* bias, flo
   int d[4];
   dx_pack_dims(Cout, Cin, bf16, d);
   ConvGemmArgs a{X, ldx, Wp, bias, Y, ldy, B, N, Cin, Cout, d[1], d[0], relu, post_scale, post_shift,
-                 relu_aux, ld_aux, accumulate, lens, mask_rows, out_scale};
+                 relu_aux, ld_aux, accumulate, lens, mask_rows, out_scale, skip_halo, x_bf16, y_bf16, aux_bf16};
   hipStream_t s = (hipStream_t)stream;
   dx_prof_begin(DX_PROF_CONV_GEMM, s);
   if (bf16) { if (taps == 3) launch_conv<__bf16, 3>(a, s); else launch_conv<__bf16, 1>(a, s); }
@@ -416,16 +578,37 @@ int dx_conv_gemm(const float* X, int ldx, const void* Wp, const float* bias, flo
 }
 
 // G[taps][Cout][Cin] (fp32, caller-zeroed) += dY^T * shift(X); then dx_unpack_wgrad moves it to (Cout, Cin, taps).
-int dx_conv_wgrad(const float* dY, int ldy, const float* X, int ldx, float* G,
-                  int B, int N, int Cin, int Cout, int taps, void* stream) {
+int dx_conv_wgrad(const void* dY, int ldy, const void* X, int ldx, float* G,
+                  int B, int N, int Cin, int Cout, int taps, const int* lens, int skip_halo,
+                  int bf16, int dy_bf16, int x_bf16, void* stream) {
   DX_REQUIRE(dY && X && G, "dx_conv_wgrad: null pointer");
+  DX_REQUIRE(bf16 || !(dy_bf16 || x_bf16), "dx_conv_wgrad: bf16 storage needs bf16 operand mode");
+  const bool bf16_ok = (Cin % 8) == 0 && (ldx % 8) == 0 && (Cout % 8) == 0 && (ldy % 8) == 0;
+  DX_REQUIRE(bf16_ok || !(dy_bf16 || x_bf16), "dx_conv_wgrad: bf16-stored operands need Cin/Cout/ld multiples of 8 (Cin=%d Cout=%d)", Cin, Cout);
+  if (bf16 && bf16_ok) {   // odd tiny shapes (speaker logits) take the exact f32 kernel below
+    DX_REQUIRE(B > 0 && N > 0 && Cin > 0 && Cout > 0 && (taps == 1 || taps == 3), "dx_conv_wgrad: bad dims");
+    DX_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)dY % 16) == 0, "dx_conv_wgrad: pointers must be 16-byte aligned");
+    DX_REQUIRE(skip_halo < 0 || lens, "dx_conv_wgrad: skip_halo needs lens");
+    const int tiles = dx_cdiv(Cout, TILE) * dx_cdiv(Cin, TILE);
+    const int total_chunks = B * dx_cdiv(N, WB_BK);
+    const int ksplit = std::max(1, std::min(total_chunks, dx_cdiv(1024, tiles * taps)));
+    WgradBf16Args a{dY, ldy, dy_bf16, X, ldx, x_bf16, G, B, N, Cin, Cout, ksplit, lens, skip_halo};
+    hipStream_t s = (hipStream_t)stream;
+    dx_prof_begin(DX_PROF_WGRAD_GEMM, s);
+    if (taps == 3) hipLaunchKernelGGL(wgrad_bf16_kernel<3>, dim3(tiles, taps, ksplit), dim3(256), 0, s, a);
+    else           hipLaunchKernelGGL(wgrad_bf16_kernel<1>, dim3(tiles, taps, ksplit), dim3(256), 0, s, a);
+    dx_prof_end(DX_PROF_WGRAD_GEMM, s);
+    DX_LAUNCH_CHECK("dx_conv_wgrad(bf16)");
+    return DX_OK;
+  }
+  DX_REQUIRE(skip_halo < 0 || lens, "dx_conv_wgrad: skip_halo needs lens");
   DX_REQUIRE(B > 0 && N > 0 && Cin > 0 && Cout > 0 && (taps == 1 || taps == 3), "dx_conv_wgrad: bad dims");
   DX_REQUIRE((Cin % 4) == 0 && (ldx % 4) == 0 && (Cout % 4) == 0 && (ldy % 4) == 0, "dx_conv_wgrad: Cin/Cout/ld must be multiples of 4 (Cin=%d Cout=%d)", Cin, Cout);
   DX_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)dY % 16) == 0, "dx_conv_wgrad: pointers must be 16-byte aligned");
   const int tiles = dx_cdiv(Cout, TILE) * dx_cdiv(Cin, TILE);
   const int total_chunks = B * dx_cdiv(N, WG_BK);
   int ksplit = std::max(1, std::min(total_chunks, dx_cdiv(1024, tiles * taps)));
-  WgradArgs a{dY, ldy, X, ldx, G, B, N, Cin, Cout, ksplit};
+  WgradArgs a{(const float*)dY, ldy, (const float*)X, ldx, G, B, N, Cin, Cout, ksplit, lens, skip_halo};
   hipStream_t s = (hipStream_t)stream;
   dx_prof_begin(DX_PROF_WGRAD_GEMM, s);
   if (taps == 3) hipLaunchKernelGGL(wgrad_kernel<3>, dim3(tiles, taps, ksplit), dim3(256), 0, s, a);
@@ -445,11 +628,12 @@ int dx_unpack_wgrad(const float* G, float* grad, int Cout, int Cin, int taps, in
 }
 
 // out[c] += sum_rows X[row][c]; out is caller-initialised (bias gradients).
-int dx_colsum(const float* X, int ldx, float* out, long rows, int C, void* stream) {
+int dx_colsum(const void* X, int ldx, float* out, long rows, int C, int x_bf16, void* stream) {
   DX_REQUIRE(X && out && rows > 0 && C > 0 && ldx >= C, "dx_colsum: bad arguments");
   const int rpb = 256;
   dim3 grid(dx_cdiv(C, 256), (unsigned)((rows + rpb - 1) / rpb));
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, out, rows, C, rpb);
+  if (x_bf16) hipLaunchKernelGGL(colsum_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)X, ldx, out, rows, C, rpb);
+  else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X, ldx, out, rows, C, rpb);
   DX_LAUNCH_CHECK("dx_colsum");
   return DX_OK;
 }

@@ -122,12 +122,13 @@ class FFTBlockFn(torch.autograd.Function):
         heads = cfg['attn_nb_heads']
         s_attn, s_ln1, s_ln2 = (next_seed(), next_seed(), next_seed()) if training else (0, 0, 0)
         film = film if film is None or film.stride(-1) == 1 else film.contiguous()
-        qkv = ops.conv_gemm(x, packs['in'], in_b)
+        L = lens.i32
+        qkv = ops.conv_gemm(x, packs['in'], in_b, lens=L, halo=0)
         att, lse = ops.attention_fwd(qkv, lens.i32, heads, s_attn, p_attn)
-        z1 = ops.conv_gemm(att, packs['out'], out_b)
+        z1 = ops.conv_gemm(att, packs['out'], out_b, lens=L, halo=0)
         y1, mean1, rstd1 = ops.ln_fwd(z1, x, ln1_w, ln1_b, None, lens.i32, seed_pre=s_ln1, p_pre=p_attn)
-        h = ops.conv_gemm(y1, packs['c1'], c1_b, relu=True)
-        z2 = ops.conv_gemm(h, packs['c2'], c2_b)
+        h = ops.conv_gemm(y1, packs['c1'], c1_b, relu=True, lens=L, halo=1, out_dtype=ops.hidden_dtype())   # conv2 reads one row past the end
+        z2 = ops.conv_gemm(h, packs['c2'], c2_b, lens=L, halo=0)
         y2, mean2, rstd2 = ops.ln_fwd(z2, y1, ln2_w, ln2_b, film, lens.i32, seed_pre=s_ln2, p_pre=p_conv)
         ctx.save_for_backward(x, film, qkv, att, lse, z1, mean1, rstd1, y1, h, z2, mean2, rstd2, ln1_w, ln1_b, ln2_w, ln2_b)
         ctx.lens, ctx.packs, ctx.heads = lens, packs, heads
@@ -143,22 +144,23 @@ class FFTBlockFn(torch.autograd.Function):
         dz2, da2, dln2_w, dln2_b, dfilm = ops.ln_bwd(dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, lens.i32,
                                                       want_da=p_conv > 0, seed_pre=s_ln2, p_pre=p_conv)
         dff = da2 if da2 is not None else dz2
-        dc2_w = ops.conv_wgrad(dff, h, packs['c2'])
+        L = lens.i32
+        dc2_w = ops.conv_wgrad(dff, h, packs['c2'], L, 0)
         dc2_b = ops.colsum(dff)
-        dh = ops.conv_gemm(dff, packs['c2'], None, transpose=True, relu_aux=h)
-        dc1_w = ops.conv_wgrad(dh, y1, packs['c1'])
+        dh = ops.conv_gemm(dff, packs['c2'], None, transpose=True, relu_aux=h, lens=L, halo=1, out_dtype=h.dtype)
+        dc1_w = ops.conv_wgrad(dh, y1, packs['c1'], L, 1)
         dc1_b = ops.colsum(dh)
-        dy1 = ops.conv_gemm(dh, packs['c1'], None, transpose=True, out=dz2, accumulate=True)  # + residual branch
+        dy1 = ops.conv_gemm(dh, packs['c1'], None, transpose=True, out=dz2, accumulate=True, lens=L, halo=0)  # + residual branch
         dz1, da1, dln1_w, dln1_b, _ = ops.ln_bwd(dy1, z1, mean1, rstd1, ln1_w, ln1_b, None, lens.i32,
                                                   want_da=p_attn > 0, seed_pre=s_ln1, p_pre=p_attn)
         dproj = da1 if da1 is not None else dz1
-        dout_w = ops.conv_wgrad(dproj, att, packs['out'])
+        dout_w = ops.conv_wgrad(dproj, att, packs['out'], L, 0)
         dout_b = ops.colsum(dproj)
-        datt = ops.conv_gemm(dproj, packs['out'], None, transpose=True)
+        datt = ops.conv_gemm(dproj, packs['out'], None, transpose=True, lens=L, halo=0)
         dqkv = ops.attention_bwd(qkv, att, datt, lse, lens.i32, ctx.heads, s_attn, p_attn)
-        din_w = ops.conv_wgrad(dqkv, x, packs['in'])
+        din_w = ops.conv_wgrad(dqkv, x, packs['in'], L, 0)
         din_b = ops.colsum(dqkv)
-        dx = ops.conv_gemm(dqkv, packs['in'], None, transpose=True, out=dz1, accumulate=True)  # + residual branch
+        dx = ops.conv_gemm(dqkv, packs['in'], None, transpose=True, out=dz1, accumulate=True, lens=L, halo=0)  # + residual branch
         return (dx, dfilm, None, None, None, None,
                 din_w, din_b, dout_w, dout_b, dln1_w, dln1_b, dc1_w, dc1_b, dc2_w, dc2_b, dln2_w, dln2_b)
 
@@ -173,11 +175,12 @@ class AccentFrontFn(torch.autograd.Function):
         p = p_drop if training else 0.0
         seeds = [next_seed() if training else 0 for _ in range(3)]
         x0 = ops.transpose(mel.contiguous())                                   # (B, T, n_mel) channels-last
-        h0 = ops.conv_gemm(x0, packs['p0'], c0_b, relu=True)
+        L = lens.i32
+        h0 = ops.conv_gemm(x0, packs['p0'], c0_b, relu=True, lens=L, halo=2)   # three stacked k=3 convs: halos 2, 1, 0
         y0, m0, r0 = ops.ln_fwd(h0, None, l0_w, l0_b, None, None, seed_post=seeds[0], p_post=p)
-        h1 = ops.conv_gemm(y0, packs['p1'], c1_b, relu=True)
+        h1 = ops.conv_gemm(y0, packs['p1'], c1_b, relu=True, lens=L, halo=1)
         y1, m1, r1 = ops.ln_fwd(h1, None, l1_w, l1_b, None, None, seed_post=seeds[1], p_post=p)
-        h2 = ops.conv_gemm(y1, packs['p2'], c2_b, relu=True)
+        h2 = ops.conv_gemm(y1, packs['p2'], c2_b, relu=True, lens=L, halo=0)
         y2, m2, r2 = ops.ln_fwd(h2, None, l2_w, l2_b, None, None, seed_post=seeds[2], p_post=p)
         energy, pitch = energy.contiguous(), pitch.contiguous()
         out = ops.accent_sum(y2, energy, pitch, we, be, wp, bp, pe, lens.i32)
@@ -192,15 +195,16 @@ class AccentFrontFn(torch.autograd.Function):
         dout = ops.mask_rows(dout.contiguous(), lens.i32)
         dwe, dbe, dwp, dbp = ops.scalar_conv_wgrad(dout, energy, pitch, lens.i32)
         dz2, _, dl2_w, dl2_b, _ = ops.ln_bwd(dout, h2, m2, r2, l2_w, l2_b, None, None, relu_mask=True, seed_post=seeds[2], p_post=p)
-        dc2_w = ops.conv_wgrad(dz2, y1, packs['p2'])
+        L = lens.i32
+        dc2_w = ops.conv_wgrad(dz2, y1, packs['p2'], L, 0)
         dc2_b = ops.colsum(dz2)
-        dy1 = ops.conv_gemm(dz2, packs['p2'], None, transpose=True)
+        dy1 = ops.conv_gemm(dz2, packs['p2'], None, transpose=True, lens=L, halo=1)
         dz1, _, dl1_w, dl1_b, _ = ops.ln_bwd(dy1, h1, m1, r1, l1_w, l1_b, None, None, relu_mask=True, seed_post=seeds[1], p_post=p)
-        dc1_w = ops.conv_wgrad(dz1, y0, packs['p1'])
+        dc1_w = ops.conv_wgrad(dz1, y0, packs['p1'], L, 1)
         dc1_b = ops.colsum(dz1)
-        dy0 = ops.conv_gemm(dz1, packs['p1'], None, transpose=True)
+        dy0 = ops.conv_gemm(dz1, packs['p1'], None, transpose=True, lens=L, halo=2)
         dz0, _, dl0_w, dl0_b, _ = ops.ln_bwd(dy0, h0, m0, r0, l0_w, l0_b, None, None, relu_mask=True, seed_post=seeds[0], p_post=p)
-        dc0_w = ops.conv_wgrad(dz0, x0, packs['p0'])
+        dc0_w = ops.conv_wgrad(dz0, x0, packs['p0'], L, 2)
         dc0_b = ops.colsum(dz0)
         return (None, None, None, None, None, None, None, None,
                 dc0_w, dc0_b, dl0_w, dl0_b, dc1_w, dc1_b, dl1_w, dl1_b, dc2_w, dc2_b, dl2_w, dl2_b, dwe, dbe, dwp, dbp)
@@ -280,7 +284,7 @@ class MelProjectionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, pack, lens):
-        mel_cl = ops.conv_gemm(x, pack, bias, lens=lens.i32, mask_rows=True)
+        mel_cl = ops.conv_gemm(x, pack, bias, lens=lens.i32, mask_rows=True, halo=0)
         ctx.save_for_backward(x)
         ctx.pack, ctx.lens = pack, lens
         return ops.transpose(mel_cl)
@@ -289,7 +293,7 @@ class MelProjectionFn(torch.autograd.Function):
     def backward(ctx, dmel):
         (x,) = ctx.saved_tensors
         d_cl = ops.mask_rows(ops.transpose(dmel.contiguous()), ctx.lens.i32)
-        dw = ops.conv_wgrad(d_cl, x, ctx.pack)
+        dw = ops.conv_wgrad(d_cl, x, ctx.pack, ctx.lens.i32, 0)
         db = ops.colsum(d_cl)
-        dx = ops.conv_gemm(d_cl, ctx.pack, None, transpose=True)
+        dx = ops.conv_gemm(d_cl, ctx.pack, None, transpose=True, lens=ctx.lens.i32, halo=0)
         return dx, dw, db, None, None

@@ -82,12 +82,13 @@ class _LossFn(torch.autograd.Function):
             # frozen predictor on the predicted mel, channels-last; gradient flows through it to the mel only
             x = ops.transpose(mel_pred)                                          # (B, T, M)
             acts = []
-            for layer in pitch_layers[:-1]:
-                r = ops.conv_gemm(x, layer['pack'], layer['b'], relu=True)
+            depth = len(pitch_layers) - 1                                       # stacked k=3 convs: halos 3, 2, 1, 0
+            for i, layer in enumerate(pitch_layers[:-1]):
+                r = ops.conv_gemm(x, layer['pack'], layer['b'], relu=True, lens=lens.i32, halo=depth - i)
                 acts.append(r)
                 x = ops.channel_affine(r, layer['scale'], layer['shift'])
             last = pitch_layers[-1]
-            pp = ops.conv_gemm(x, last['pack'], last['b'])[:, :, 0].contiguous()  # (B, T)
+            pp = ops.conv_gemm(x, last['pack'], last['b'], lens=lens.i32, halo=0)[:, :, 0].contiguous()  # (B, T)
             frames_pitch = frames_pitch.contiguous()
             psum = ops.pitch_mse(pp, frames_pitch, lens.i32)
             terms[6:7] = psum[0] / (psum[1] + 1e-5)
@@ -98,8 +99,8 @@ class _LossFn(torch.autograd.Function):
             for k in range(len(pitch_layers) - 1, 0, -1):
                 prev = pitch_layers[k - 1]
                 g = ops.conv_gemm(g, pitch_layers[k]['pack'], None, transpose=True, post_scale=prev['scale'], post_shift=prev['zeros'],
-                                  relu_aux=acts[k - 1])
-            d = ops.conv_gemm(g, pitch_layers[0]['pack'], None, transpose=True)
+                                  relu_aux=acts[k - 1], lens=lens.i32, halo=depth - k + 1)
+            d = ops.conv_gemm(g, pitch_layers[0]['pack'], None, transpose=True, lens=lens.i32, halo=0)
             dmel = dmel + ops.transpose(d)
         total = terms[0] + terms[2] + terms[3] + terms[4] + cfg['ecw'] * terms[5] + cfg['pcw'] * terms[6]
         ctx.save_for_backward(dmel, d_spk, d_pm)

@@ -48,9 +48,18 @@ def _stream():
 
 
 def _chk(t, name):
-    if not t.is_cuda or t.dtype != torch.float32:
-        raise TypeError(f'{name} must be a float32 tensor on the GPU (got {t.dtype} on {t.device})')
+    if not t.is_cuda or t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f'{name} must be a float32 (or, in bf16 mode, bfloat16) tensor on the GPU (got {t.dtype} on {t.device})')
     return t
+
+
+def _is_bf16(t):
+    return int(t is not None and t.dtype == torch.bfloat16)
+
+
+def hidden_dtype():
+    """Storage type of the 1024-wide hidden activations: bf16 in bf16 operand mode (their HBM traffic bounds the step)."""
+    return torch.bfloat16 if _PRECISION['bf16'] else torch.float32
 
 
 def _rows(t):
@@ -93,7 +102,8 @@ class PackedWeight:
 
 
 def conv_gemm(x, pack: PackedWeight, bias=None, *, transpose=False, relu=False, post_scale=None, post_shift=None,
-              relu_aux=None, out=None, accumulate=False, lens=None, mask_rows=False, out_scale=1.0, B=None, N=None):
+              relu_aux=None, out=None, accumulate=False, lens=None, mask_rows=False, out_scale=1.0, B=None, N=None, halo=-1,
+              out_dtype=torch.float32):
     """y = epilogue(conv(x)).  ``transpose=True`` runs the input-gradient convolution (x is dY, result is dX)."""
     _chk(x, 'x')
     pack.refresh()
@@ -106,23 +116,25 @@ def conv_gemm(x, pack: PackedWeight, bias=None, *, transpose=False, relu=False, 
         raise ValueError(f'expected {cin} input channels, got {x.shape[-1]}')
     ldx = _rows(x)
     if out is None:
-        out = torch.empty(*x.shape[:-1], cout, dtype=torch.float32, device=x.device)
+        out = torch.empty(*x.shape[:-1], cout, dtype=out_dtype, device=x.device)
     ldy = _rows(out)
     if _LAUNCH_LOG[0] is not None:
         _LAUNCH_LOG[0].append(('conv', B_ * N_, N_, cin, cout, pack.taps))
     lib().dx_conv_gemm(_p(x), ldx, _p(pack.bwd if transpose else pack.fwd), _p(bias), _p(out), ldy, B_, N_, cin, cout, pack.taps,
                        pack.bf16, int(relu), _p(post_scale), _p(post_shift), _p(relu_aux),
-                       0 if relu_aux is None else _rows(relu_aux), int(accumulate), _p(lens), int(mask_rows), float(out_scale), _stream())
+                       0 if relu_aux is None else _rows(relu_aux), int(accumulate), _p(lens), int(mask_rows), float(out_scale), int(halo),
+                       _is_bf16(x), _is_bf16(out), _is_bf16(relu_aux), _stream())
     return out
 
 
-def conv_wgrad(dy, x, pack: PackedWeight):
+def conv_wgrad(dy, x, pack: PackedWeight, lens=None, halo=-1):
     """Gradient w.r.t. the (Cout, Cin[, taps]) parameter, in the parameter's own layout."""
     B_, N_ = (1, x.shape[0]) if x.dim() == 2 else (x.shape[0], x.shape[1])
     g = torch.zeros(pack.taps * pack.cout * pack.cin, dtype=torch.float32, device=x.device)
     if _LAUNCH_LOG[0] is not None:
         _LAUNCH_LOG[0].append(('wgrad', B_ * N_, N_, pack.cin, pack.cout, pack.taps))
-    lib().dx_conv_wgrad(_p(dy), _rows(dy), _p(x), _rows(x), _p(g), B_, N_, pack.cin, pack.cout, pack.taps, _stream())
+    lib().dx_conv_wgrad(_p(dy), _rows(dy), _p(x), _rows(x), _p(g), B_, N_, pack.cin, pack.cout, pack.taps, _p(lens), int(halo),
+                        _PRECISION['bf16'], _is_bf16(dy), _is_bf16(x), _stream())
     if pack.taps == 1:
         return g.view(pack.weight.shape)
     grad = torch.empty(pack.weight.shape, dtype=torch.float32, device=x.device)
@@ -134,7 +146,7 @@ def colsum(x, C=None):
     C = x.shape[-1] if C is None else C
     rows = x.numel() // x.shape[-1]
     out = torch.zeros(C, dtype=torch.float32, device=x.device)
-    lib().dx_colsum(_p(x), _rows(x), _p(out), rows, C, _stream())
+    lib().dx_colsum(_p(x), _rows(x), _p(out), rows, C, _is_bf16(x), _stream())
     return out
 
 
