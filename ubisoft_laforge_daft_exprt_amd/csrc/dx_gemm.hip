@@ -16,7 +16,7 @@
 // batch row; a wave owns 64x64 as 4x4 MFMA tiles of 16x16.  W is the MFMA "A" operand (rows = channels),
 // X the "B" operand (columns = tokens), so every lane ends up with 4 consecutive output channels of one
 // token: 16-byte stores, and per-channel epilogue vectors are 16-byte loads.  Both operands sit in LDS as
-// [row][128 bytes of K] (+16 B pad); a lane fetches its whole fragment for 16 (f32) / 32 (bf16) K values
+// [row][128 bytes of K] (XOR-swizzled 16-byte slots); a lane fetches its whole fragment for 16 (f32) / 32 (bf16) K values
 // with one ds_read_b128.  For f32 the K index inside a 16-wide group is permuted (lane group g, element j
 // <-> k = 4g + j) identically for both operands, which leaves the sum unchanged.
 // The token tile is staged once per K chunk WITH a one-row halo on both sides; the three taps read it at
@@ -28,7 +28,6 @@
 namespace {
 
 constexpr int TILE = 128;   // channels and tokens per workgroup
-constexpr int ROWB = 144;   // LDS row stride in bytes: 128 B of K + 16 B pad
 
 struct ConvGemmArgs {
   const float* X; int ldx;
@@ -61,35 +60,55 @@ template <> struct Mma<__bf16> {
   }
 };
 
+__device__ __forceinline__ uint2 pack_bf16x4v(const f32x4& v) {
+  bf16x4 h;
+  h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+  return __builtin_bit_cast(uint2, h);
+}
+
 __device__ __forceinline__ uint2 pack_bf16x4(const float4& v) {
   bf16x4 h;
   h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
   return __builtin_bit_cast(uint2, h);
 }
 
-template <typename T, int TAPS>
+// LDS image of both operands: unpadded 128-byte rows, 16-byte slot index XOR-ed with (row & 7).  The fragment read of a
+// 16-lane ds_read_b128 group then touches 16 distinct bank slots for every tap offset (0/1/2 rows): conflict free, and the
+// tile needs 65 KB instead of 74 KB (two workgroups per CU with room to spare).
+__device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
+
+// TOK = tokens per workgroup (128, or 64 for narrow outputs that would otherwise launch fewer workgroups than CUs).
+// XH  = the activation tensor is stored as bf16 (bf16 operand mode only).
+// Software pipeline: the global loads of K-chunk c+1 are issued into registers before the MFMAs of chunk c and written
+// to LDS after them, so HBM/L2 latency hides under the matrix work of the same wave.
+template <typename T, int TAPS, int TOK, bool XH>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a) {
   constexpr int PAD = (TAPS - 1) / 2;
   constexpr int BK = 128 / (int)sizeof(T);
-  constexpr int XROWS = TILE + TAPS - 1;
+  constexpr int XROWS = TOK + TAPS - 1;
+  constexpr int NJ = TOK / 32;                      // 16-token sub-tiles per wave
+  constexpr int W_IT = TAPS * TILE * 8 / 256;       // 16-byte weight units per thread per chunk
+  constexpr bool CVT = (sizeof(T) == 2) && !XH;     // fp32 activations converted to bf16 while staging
+  constexpr int XU = CVT ? 16 : 8;                  // 16-byte global units per activation row per chunk
+  constexpr int XE = XH ? 8 : 4;                    // elements per unit
+  constexpr int X_IT = (XROWS * XU + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Ws = smem;
-  unsigned char* Xs = smem + TAPS * TILE * ROWB;
+  unsigned char* Xs = smem + TAPS * TILE * 128;
 
-  const int tiles_n = (a.N + TILE - 1) / TILE;
+  const int tiles_n = (a.N + TOK - 1) / TOK;
   const int b = blockIdx.x / tiles_n;
-  const int n0 = (blockIdx.x - b * tiles_n) * TILE;
+  const int n0 = (blockIdx.x - b * tiles_n) * TOK;
   const int co0 = blockIdx.y * TILE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wc = wave >> 1, wt = wave & 1;
   const int r = lane & 15, g = lane >> 4;
   const T* Wp = reinterpret_cast<const T*>(a.Wp);
-  const float* Xb = a.X + (size_t)b * a.N * a.ldx;
 
   if (a.skip_halo >= 0 && n0 >= a.lens[b] + a.skip_halo) {
     // whole tile is padding beyond the halo: nothing downstream reads it with a non-zero weight; keep it defined
     if (!a.accumulate) {
-      for (int u = tid; u < TILE * 32; u += 256) {
+      for (int u = tid; u < TOK * 32; u += 256) {
         const int row = u >> 5, q = u & 31;
         const int n = n0 + row, co = co0 + q * 4;
         if (n < a.N && co < a.Cout) {
@@ -107,66 +126,73 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
     return;
   }
 
-  f32x4 acc[4][4];
+  // prefetch registers; plain macros (not lambdas) so that the arrays are provably register-resident
+  f32x4 wreg[W_IT], xreg[X_IT];                      // native vectors: SROA keeps them in VGPRs
+#define DX_LOAD_CHUNK(CH)                                                                                                        \
+  {                                                                                                                              \
+    const int ci0_ = (CH) * BK;                                                                                                  \
+    _Pragma("unroll") for (int it = 0; it < W_IT; ++it) {                                                                        \
+      const int u = tid + it * 256;                                                                                              \
+      const int row = u >> 3, q = u & 7;                                                                                         \
+      const int tap = row >> 7, col = row & (TILE - 1);                                                                          \
+      wreg[it] = *reinterpret_cast<const f32x4*>(Wp + ((size_t)(tap * a.CoutP + co0 + col) * a.CinP + ci0_) + q * (16 / (int)sizeof(T))); \
+    }                                                                                                                            \
+    _Pragma("unroll") for (int it = 0; it < X_IT; ++it) {                                                                        \
+      const int u = tid + it * 256;                                                                                              \
+      const int row = u / XU, q = u % XU;                                                                                        \
+      const int n = n0 + row - PAD, ci = ci0_ + q * XE;                                                                          \
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                                                       \
+      if (u < XROWS * XU && n >= 0 && n < a.N && ci < a.Cin) {                                                                   \
+        if constexpr (XH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.X) + ((size_t)b * a.N + n) * a.ldx + ci); \
+        else v = *reinterpret_cast<const f32x4*>(a.X + ((size_t)b * a.N + n) * a.ldx + ci);                                      \
+      }                                                                                                                          \
+      xreg[it] = v;                                                                                                              \
+    }                                                                                                                            \
+  }
+#define DX_STORE_CHUNK()                                                                                                         \
+  {                                                                                                                              \
+    _Pragma("unroll") for (int it = 0; it < W_IT; ++it) {                                                                        \
+      const int u = tid + it * 256;                                                                                              \
+      *reinterpret_cast<f32x4*>(Ws + lds_off(u >> 3, u & 7)) = wreg[it];                                                        \
+    }                                                                                                                            \
+    _Pragma("unroll") for (int it = 0; it < X_IT; ++it) {                                                                        \
+      const int u = tid + it * 256;                                                                                              \
+      const int row = u / XU, q = u % XU;                                                                                        \
+      if (u < XROWS * XU) {                                                                                                      \
+        if constexpr (CVT) *reinterpret_cast<uint2*>(Xs + lds_off(row, q >> 1) + ((q & 1) << 3)) = pack_bf16x4v(xreg[it]);       \
+        else *reinterpret_cast<f32x4*>(Xs + lds_off(row, q)) = xreg[it];                                                         \
+      }                                                                                                                          \
+    }                                                                                                                            \
+  }
+
+  f32x4 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nchunks = a.CinP / BK;
+  DX_LOAD_CHUNK(0);
   for (int ch = 0; ch < nchunks; ++ch) {
-    const int ci0 = ch * BK;
+    __syncthreads();                       // every wave is done reading the previous chunk
+    DX_STORE_CHUNK();
     __syncthreads();
-    // weights: TAPS*128 rows x 8 sixteen-byte units, no bounds (the pack is zero padded)
-    for (int u = tid; u < TAPS * TILE * 8; u += 256) {
-      const int row = u >> 3, q = u & 7;
-      const int tap = row >> 7, col = row & (TILE - 1);
-      const T* src = Wp + ((size_t)(tap * a.CoutP + co0 + col) * a.CinP + ci0) + q * (16 / (int)sizeof(T));
-      *reinterpret_cast<float4*>(Ws + row * ROWB + q * 16) = *reinterpret_cast<const float4*>(src);
-    }
-    // activations with halo rows; zero outside the batch row / beyond Cin
-    if constexpr (sizeof(T) == 4) {
-      for (int u = tid; u < XROWS * 8; u += 256) {
-        const int row = u >> 3, q = u & 7;
-        const int n = n0 + row - PAD, ci = ci0 + q * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n >= 0 && n < a.N && ci < a.Cin) v = *reinterpret_cast<const float4*>(Xb + (size_t)n * a.ldx + ci);
-        *reinterpret_cast<float4*>(Xs + row * ROWB + q * 16) = v;
-      }
-    } else if (a.x_bf16) {
-      const __bf16* Xh = reinterpret_cast<const __bf16*>(a.X) + (size_t)b * a.N * a.ldx;
-      for (int u = tid; u < XROWS * 8; u += 256) {
-        const int row = u >> 3, q = u & 7;
-        const int n = n0 + row - PAD, ci = ci0 + q * 8;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n >= 0 && n < a.N && ci < a.Cin) v = *reinterpret_cast<const float4*>(Xh + (size_t)n * a.ldx + ci);
-        *reinterpret_cast<float4*>(Xs + row * ROWB + q * 16) = v;
-      }
-    } else {
-      for (int u = tid; u < XROWS * 16; u += 256) {
-        const int row = u >> 4, q = u & 15;
-        const int n = n0 + row - PAD, ci = ci0 + q * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n >= 0 && n < a.N && ci < a.Cin) v = *reinterpret_cast<const float4*>(Xb + (size_t)n * a.ldx + ci);
-        *reinterpret_cast<uint2*>(Xs + row * ROWB + q * 8) = pack_bf16x4(v);
-      }
-    }
-    __syncthreads();
+    if (ch + 1 < nchunks) DX_LOAD_CHUNK(ch + 1);
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        float4 wf[4], xf[4];
+        float4 wf[4], xf[NJ];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          wf[i] = *reinterpret_cast<const float4*>(Ws + (tap * TILE + wc * 64 + i * 16 + r) * ROWB + ks * 64 + g * 16);
+          wf[i] = *reinterpret_cast<const float4*>(Ws + lds_off(tap * TILE + wc * 64 + i * 16 + r, ks * 4 + g));
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          xf[j] = *reinterpret_cast<const float4*>(Xs + (wt * 64 + j * 16 + r + tap) * ROWB + ks * 64 + g * 16);
+        for (int j = 0; j < NJ; ++j)
+          xf[j] = *reinterpret_cast<const float4*>(Xs + lds_off(wt * (TOK / 2) + j * 16 + r + tap, ks * 4 + g));
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
+          for (int j = 0; j < NJ; ++j) Mma<T>::run(wf[i], xf[j], acc[i][j]);
       }
     }
   }
@@ -187,8 +213,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
       }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wt * 64 + j * 16 + r;
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + wt * (TOK / 2) + j * 16 + r;
       if (n >= a.N) continue;
       const size_t row = (size_t)b * a.N + n;
       float v[4];
@@ -233,6 +259,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
     }
   }
 }
+
+#undef DX_LOAD_CHUNK
+#undef DX_STORE_CHUNK
 
 // ------------------------------------------------------------------------------------------------
 // weight gradient: G[tap][co][ci] += sum over tokens of dY[token][co] * X[token + tap - PAD][ci]
@@ -358,85 +387,131 @@ __device__ __forceinline__ bf16x8 tr_fragment(const __bf16* tile, int row0, int 
   return __builtin_bit_cast(bf16x8, v);
 }
 
-// stage `rows` token rows (first = n_first, may be < 0 or >= N -> zeros) x 128 channels starting at c0 as bf16
-__device__ __forceinline__ void stage_bf16(__bf16* dst, const void* src, int ld, int is_bf16, size_t batch_off, int n_first, int rows,
-                                           int c0, int C, int N, int tid) {
-  if (is_bf16) {
-    const __bf16* base = reinterpret_cast<const __bf16*>(src) + batch_off;
-    for (int u = tid; u < rows * 16; u += 256) {
-      const int row = u >> 4, q = u & 15;
-      const int n = n_first + row, c = c0 + q * 8;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n >= 0 && n < N && c < C) v = *reinterpret_cast<const float4*>(base + (size_t)n * ld + c);
-      *reinterpret_cast<float4*>(dst + row * WB_LD + q * 8) = v;
-    }
-  } else {
-    const float* base = reinterpret_cast<const float*>(src) + batch_off;
-    for (int u = tid; u < rows * 32; u += 256) {
-      const int row = u >> 5, q = u & 31;
-      const int n = n_first + row, c = c0 + q * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n >= 0 && n < N && c < C) v = *reinterpret_cast<const float4*>(base + (size_t)n * ld + c);
-      *reinterpret_cast<uint2*>(dst + row * WB_LD + q * 4) = pack_bf16x4(v);
-    }
-  }
-}
-
-template <int TAPS>
+template <int TAPS, bool DYH, bool XH>
 __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBf16Args a) {
+  // workgroup: 128 output channels x 64 input channels x ALL taps; wave (2x2): 64 co x 32 ci -> 4 x 2 x TAPS MFMA tiles.
+  // The dY tile and the (halo-extended) X tile are staged once per 64-token chunk and shared by the taps.
   constexpr int PAD = (TAPS - 1) / 2;
+  constexpr int CI_T = 64;
+  constexpr int XROWS = WB_BK + TAPS - 1;
+  constexpr int DU = DYH ? 16 : 32, DE = DYH ? 8 : 4;     // 16-byte global units per dY row (128 channels), elements per unit
+  constexpr int XU = XH ? 8 : 16, XE = XH ? 8 : 4;         // per X row (64 channels)
+  constexpr int D_IT = WB_BK * DU / 256;
+  constexpr int X_IT = (XROWS * XU + 255) / 256;
   __shared__ __attribute__((aligned(16))) __bf16 Ds[WB_BK * WB_LD];
-  __shared__ __attribute__((aligned(16))) __bf16 Xs[(WB_BK + 8) * WB_LD];   // +2 halo rows, padded so every tr read stays in bounds
-  const int ci_tiles = (a.Cin + TILE - 1) / TILE;
+  __shared__ __attribute__((aligned(16))) __bf16 Xs[(WB_BK + 8) * WB_LD];   // rows beyond the halo stay zero so every tr read is in bounds
+  const int ci_tiles = (a.Cin + CI_T - 1) / CI_T;
   const int co0 = (blockIdx.x / ci_tiles) * TILE;
-  const int ci0 = (blockIdx.x % ci_tiles) * TILE;
-  const int tap = blockIdx.y;
+  const int ci0 = (blockIdx.x % ci_tiles) * CI_T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wc = wave >> 1, wt = wave & 1;
   const int r = lane & 15, g = lane >> 4;
   const int chunks_per_row = (a.N + WB_BK - 1) / WB_BK;
   const int total = a.B * chunks_per_row;
 
-  f32x4 acc[4][4];
+  f32x4 acc[TAPS][4][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int u = tid; u < 8 * WB_LD; u += 256) Xs[(WB_BK) * WB_LD + u] = (__bf16)0.f;   // rows 64..71 (halo rows 64, 65 rewritten per chunk)
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int u = tid; u < 8 * WB_LD; u += 256) Xs[WB_BK * WB_LD + u] = (__bf16)0.f;
 
-  for (int c = blockIdx.z; c < total; c += a.ksplit) {
-    const int b = c / chunks_per_row;
-    const int nc = (c - b * chunks_per_row) * WB_BK;
-    if (a.skip_halo >= 0 && nc >= a.lens[b] + a.skip_halo) continue;
+  f32x4 dreg[D_IT], xreg[X_IT];
+#define DX_WG_LOAD(B_, NC_)                                                                                                   \
+  {                                                                                                                           \
+    _Pragma("unroll") for (int it = 0; it < D_IT; ++it) {                                                                     \
+      const int u = tid + it * 256;                                                                                           \
+      const int row = u / DU, q = u % DU;                                                                                     \
+      const int n = (NC_) + row, c = co0 + q * DE;                                                                            \
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                                                    \
+      if (n < a.N && c < a.Cout) {                                                                                            \
+        if constexpr (DYH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.dY) + ((size_t)(B_) * a.N + n) * a.ldy + c); \
+        else v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.dY) + ((size_t)(B_) * a.N + n) * a.ldy + c); \
+      }                                                                                                                       \
+      dreg[it] = v;                                                                                                           \
+    }                                                                                                                         \
+    _Pragma("unroll") for (int it = 0; it < X_IT; ++it) {                                                                     \
+      const int u = tid + it * 256;                                                                                           \
+      const int row = u / XU, q = u % XU;                                                                                     \
+      const int n = (NC_) - PAD + row, c = ci0 + q * XE;                                                                      \
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                                                    \
+      if (u < XROWS * XU && n >= 0 && n < a.N && c < a.Cin) {                                                                 \
+        if constexpr (XH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.X) + ((size_t)(B_) * a.N + n) * a.ldx + c); \
+        else v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.X) + ((size_t)(B_) * a.N + n) * a.ldx + c); \
+      }                                                                                                                       \
+      xreg[it] = v;                                                                                                           \
+    }                                                                                                                         \
+  }
+#define DX_WG_STORE()                                                                                                         \
+  {                                                                                                                           \
+    _Pragma("unroll") for (int it = 0; it < D_IT; ++it) {                                                                     \
+      const int u = tid + it * 256;                                                                                           \
+      const int row = u / DU, q = u % DU;                                                                                     \
+      if constexpr (DYH) *reinterpret_cast<f32x4*>(Ds + row * WB_LD + q * 8) = dreg[it];                                      \
+      else *reinterpret_cast<uint2*>(Ds + row * WB_LD + q * 4) = pack_bf16x4v(dreg[it]);                                      \
+    }                                                                                                                         \
+    _Pragma("unroll") for (int it = 0; it < X_IT; ++it) {                                                                     \
+      const int u = tid + it * 256;                                                                                           \
+      const int row = u / XU, q = u % XU;                                                                                     \
+      if (u < XROWS * XU) {                                                                                                   \
+        if constexpr (XH) *reinterpret_cast<f32x4*>(Xs + row * WB_LD + q * 8) = xreg[it];                                     \
+        else *reinterpret_cast<uint2*>(Xs + row * WB_LD + q * 4) = pack_bf16x4v(xreg[it]);                                    \
+      }                                                                                                                       \
+    }                                                                                                                         \
+  }
+
+  // first live chunk of this split-K slice (interleaved: every slice sees a mix of utterance lengths)
+  int c = blockIdx.z;
+  auto live = [&](int cc, int& b_, int& nc_) {
+    b_ = cc / chunks_per_row;
+    nc_ = (cc - b_ * chunks_per_row) * WB_BK;
+    return !(a.skip_halo >= 0 && nc_ >= a.lens[b_] + a.skip_halo);
+  };
+  int b = 0, nc = 0;
+  while (c < total && !live(c, b, nc)) c += a.ksplit;
+  if (c < total) DX_WG_LOAD(b, nc);
+  while (c < total) {
     __syncthreads();
-    stage_bf16(Ds, a.dY, a.ldy, a.dy_bf16, (size_t)b * a.N * a.ldy, nc, WB_BK, co0, a.Cout, a.N, tid);
-    stage_bf16(Xs, a.X, a.ldx, a.x_bf16, (size_t)b * a.N * a.ldx, nc - PAD, WB_BK + TAPS - 1, ci0, a.Cin, a.N, tid);
+    DX_WG_STORE();
     __syncthreads();
+    c += a.ksplit;
+    while (c < total && !live(c, b, nc)) c += a.ksplit;
+    if (c < total) DX_WG_LOAD(b, nc);
 #pragma unroll
     for (int ks = 0; ks < WB_BK / 32; ++ks) {
-      bf16x8 df[4], xf[4];
+      bf16x8 df[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) df[i] = tr_fragment(Ds, ks * 32, wc * 64 + i * 16, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xf[j] = tr_fragment(Xs, ks * 32 + tap, wt * 64 + j * 16, lane);
+      for (int t = 0; t < TAPS; ++t) {
+        bf16x8 xf[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 2; ++j) xf[j] = tr_fragment(Xs, ks * 32 + t, wt * 32 + j * 16, lane);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[i], xf[j], acc[i][j], 0, 0, 0);
-    }
-  }
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int ci = ci0 + wt * 64 + j * 16 + r;
-      if (ci >= a.Cin) continue;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int co = co0 + wc * 64 + i * 16 + g * 4 + e;
-        if (co < a.Cout && acc[i][j][e] != 0.f) atomicAdd(&a.G[((size_t)tap * a.Cout + co) * a.Cin + ci], acc[i][j][e]);
+          for (int j = 0; j < 2; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[i], xf[j], acc[t][i][j], 0, 0, 0);
       }
     }
+  }
+#undef DX_WG_LOAD
+#undef DX_WG_STORE
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ci = ci0 + wt * 32 + j * 16 + r;
+        if (ci >= a.Cin) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int co = co0 + wc * 64 + i * 16 + g * 4 + e;
+          if (co < a.Cout && acc[t][i][j][e] != 0.f) atomicAdd(&a.G[((size_t)t * a.Cout + co) * a.Cin + ci], acc[t][i][j][e]);
+        }
+      }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -498,16 +573,26 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, in
   if (t != 0.f) atomicAdd(&out[c], t);
 }
 
-template <typename T, int TAPS>
-int launch_conv(const ConvGemmArgs& a, hipStream_t s) {
-  const size_t smem = (size_t)(TAPS * TILE + TILE + TAPS - 1) * ROWB;
+template <typename T, int TAPS, int TOK, bool XH>
+void launch_conv_inst(const ConvGemmArgs& a, hipStream_t s) {
+  const size_t smem = (size_t)(TAPS * TILE + TOK + TAPS - 1) * 128;
   static bool configured = false;
   if (!configured) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, TAPS, TOK, XH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     configured = true;
   }
-  dim3 grid(a.B * dx_cdiv(a.N, TILE), a.CoutP / TILE);
-  hipLaunchKernelGGL((conv_gemm_kernel<T, TAPS>), grid, dim3(256), smem, s, a);
+  dim3 grid(a.B * dx_cdiv(a.N, TOK), a.CoutP / TILE);
+  hipLaunchKernelGGL((conv_gemm_kernel<T, TAPS, TOK, XH>), grid, dim3(256), smem, s, a);
+}
+
+template <typename T, int TAPS>
+int launch_conv(const ConvGemmArgs& a, hipStream_t s) {
+  // narrow outputs (Cout <= 128: conv2, out-proj, mel projection ...) would launch fewer workgroups than there are CUs
+  const bool small = (long)a.B * dx_cdiv(a.N, TILE) * (a.CoutP / TILE) < 1024;
+  if constexpr (sizeof(T) == 2) {
+    if (a.x_bf16) { if (small) launch_conv_inst<T, TAPS, 64, true>(a, s); else launch_conv_inst<T, TAPS, 128, true>(a, s); return DX_OK; }
+  }
+  if (small) launch_conv_inst<T, TAPS, 64, false>(a, s); else launch_conv_inst<T, TAPS, 128, false>(a, s);
   return DX_OK;
 }
 
@@ -589,14 +674,20 @@ int dx_conv_wgrad(const void* dY, int ldy, const void* X, int ldx, float* G,
     DX_REQUIRE(B > 0 && N > 0 && Cin > 0 && Cout > 0 && (taps == 1 || taps == 3), "dx_conv_wgrad: bad dims");
     DX_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)dY % 16) == 0, "dx_conv_wgrad: pointers must be 16-byte aligned");
     DX_REQUIRE(skip_halo < 0 || lens, "dx_conv_wgrad: skip_halo needs lens");
-    const int tiles = dx_cdiv(Cout, TILE) * dx_cdiv(Cin, TILE);
+    const int tiles = dx_cdiv(Cout, TILE) * dx_cdiv(Cin, 64);
     const int total_chunks = B * dx_cdiv(N, WB_BK);
-    const int ksplit = std::max(1, std::min(total_chunks, dx_cdiv(1024, tiles * taps)));
+    const int ksplit = std::max(1, std::min(total_chunks, dx_cdiv(768, tiles)));
     WgradBf16Args a{dY, ldy, dy_bf16, X, ldx, x_bf16, G, B, N, Cin, Cout, ksplit, lens, skip_halo};
     hipStream_t s = (hipStream_t)stream;
+    dim3 grid(tiles, 1, ksplit);
     dx_prof_begin(DX_PROF_WGRAD_GEMM, s);
-    if (taps == 3) hipLaunchKernelGGL(wgrad_bf16_kernel<3>, dim3(tiles, taps, ksplit), dim3(256), 0, s, a);
-    else           hipLaunchKernelGGL(wgrad_bf16_kernel<1>, dim3(tiles, taps, ksplit), dim3(256), 0, s, a);
+#define DX_WG_LAUNCH(TAPS_)                                                                                              \
+    if (dy_bf16 && x_bf16) hipLaunchKernelGGL((wgrad_bf16_kernel<TAPS_, true, true>), grid, dim3(256), 0, s, a);            \
+    else if (dy_bf16) hipLaunchKernelGGL((wgrad_bf16_kernel<TAPS_, true, false>), grid, dim3(256), 0, s, a);                \
+    else if (x_bf16) hipLaunchKernelGGL((wgrad_bf16_kernel<TAPS_, false, true>), grid, dim3(256), 0, s, a);                 \
+    else hipLaunchKernelGGL((wgrad_bf16_kernel<TAPS_, false, false>), grid, dim3(256), 0, s, a);
+    if (taps == 3) { DX_WG_LAUNCH(3) } else { DX_WG_LAUNCH(1) }
+#undef DX_WG_LAUNCH
     dx_prof_end(DX_PROF_WGRAD_GEMM, s);
     DX_LAUNCH_CHECK("dx_conv_wgrad(bf16)");
     return DX_OK;
