@@ -51,7 +51,8 @@ int dx_conv_gemm(const void* X, int ldx, const void* Wp, const float* bias, void
 /* G[taps][Cout][Cin] (fp32, caller-zeroed) += dY^T * shifted X   (autograd of the conv w.r.t. its weight) */
 int dx_conv_wgrad(const void* dY, int ldy, const void* X, int ldx, float* G,
                   int B, int N, int Cin, int Cout, int taps, const int* lens, int skip_halo,
-                  int bf16, int dy_bf16, int x_bf16, void* stream);
+                  int bf16, int dy_bf16, int x_bf16, float* dbias, void* stream);
+/* dbias (optional, caller-zeroed [Cout]): the bias gradient sum_rows dY is accumulated by the same launch from the staged dY tiles */
 /* grad (Cout, Cin, taps) (+)= G[taps][Cout][Cin] */
 int dx_unpack_wgrad(const float* G, float* grad, int Cout, int Cin, int taps, int accumulate, void* stream);
 /* out[c] += sum_rows X[row][c]   (bias gradients) */

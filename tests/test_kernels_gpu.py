@@ -56,8 +56,9 @@ def test_conv_gemm_forward_dgrad_wgrad(ops, precision, tol, B, N, Cin, Cout, tap
             dx = ops.conv_gemm(dy, pack, None, transpose=True)
             assert rel_err(dx, x.grad) < tol
             if precision == 'f32' or (Cin % 8 == 0 and Cout % 8 == 0):
-                dw = ops.conv_wgrad(dy, x.detach(), pack)
+                dw, db = ops.conv_wgrad(dy, x.detach(), pack)
                 assert rel_err(dw, w.grad) < (1e-5 if precision == 'f32' else 2e-2)
+                assert rel_err(db, b.grad) < (1e-5 if precision == 'f32' else 1e-2)     # fused bias gradient
                 assert rel_err(ops.colsum(dy), b.grad) < 1e-5
     finally:
         ops.set_precision('f32')
@@ -113,14 +114,14 @@ def test_bf16_hidden_storage(ops):
         assert rel_err(dh.float(), dh_ref) < 2e-2
         dx = ops.conv_gemm(dh, p1, None, transpose=True)
         assert rel_err(dx, x.grad) < 3e-2
-        assert rel_err(ops.conv_wgrad(dz, h, p2), dw2_ref) < 3e-2
-        assert rel_err(ops.conv_wgrad(dh, x.detach(), p1), w1.grad) < 3e-2
+        assert rel_err(ops.conv_wgrad(dz, h, p2)[0], dw2_ref) < 3e-2
+        assert rel_err(ops.conv_wgrad(dh, x.detach(), p1)[0], w1.grad) < 3e-2
         assert rel_err(ops.colsum(dh), (dh.float()).sum((0, 1))) < 1e-4
         # tile skipping keeps skipped tiles defined (zeros) for bf16 outputs too
         h2 = ops.conv_gemm(x.detach(), p1, b1, relu=True, out_dtype=torch.bfloat16, lens=lens, halo=1)
         assert torch.equal(h2[2, 128:], torch.zeros_like(h2[2, 128:])) and torch.equal(h2[0], h[0]) and torch.equal(h2[2, :128], h[2, :128])
         dzm = dz * (torch.arange(N, device=DEV)[None, :, None] < lens[:, None, None])
-        assert rel_err(ops.conv_wgrad(dzm, h, p2, lens, 0), ops.conv_wgrad(dzm, h, p2)) < 1e-5
+        assert rel_err(ops.conv_wgrad(dzm, h, p2, lens, 0)[0], ops.conv_wgrad(dzm, h, p2)[0]) < 1e-5
     finally:
         ops.set_precision('f32')
 

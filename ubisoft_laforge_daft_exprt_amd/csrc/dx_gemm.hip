@@ -275,6 +275,7 @@ struct WgradArgs {
   float* G;
   int B, N, Cin, Cout, ksplit;
   const int* lens; int skip_halo;   // chunks starting at or beyond len_b + skip_halo carry a zero dY: skipped
+  float* dbias;                     // optional: dbias[co] += column sums of dY (fused bias gradient)
 };
 
 constexpr int WG_BK = 32;     // tokens per K chunk
@@ -301,6 +302,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = a.dbias != nullptr && tap == 0 && ci0 == 0 && tid < TILE;
+  float bsum = 0.f;
 
   for (int c = blockIdx.z; c < total; c += a.ksplit) {   // interleaved split: every slice sees a mix of utterance lengths
     const int b = c / chunks_per_row;
@@ -324,6 +327,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
       *reinterpret_cast<float4*>(&Xs[row * WG_LD + q * 4]) = v;
     }
     __syncthreads();
+    if (do_bias) {
+#pragma unroll 8
+      for (int k = 0; k < WG_BK; ++k) bsum += Ds[k * WG_LD + tid];
+    }
 #pragma unroll
     for (int kg = 0; kg < WG_BK / 16; ++kg) {
       float df[4][4], xf[4][4];
@@ -356,6 +363,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         if (co < a.Cout) atomicAdd(&a.G[((size_t)tap * a.Cout + co) * a.Cin + ci], acc[i][j][e]);
       }
     }
+  if (do_bias && co0 + tid < a.Cout && bsum != 0.f) atomicAdd(&a.dbias[co0 + tid], bsum);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -374,6 +382,7 @@ struct WgradBf16Args {
   float* G;
   int B, N, Cin, Cout, ksplit;
   const int* lens; int skip_halo;
+  float* dbias;
 };
 
 __device__ __forceinline__ bf16x8 tr_fragment(const __bf16* tile, int row0, int col0, int lane) {
@@ -418,6 +427,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBf16Args 
       for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int u = tid; u < 8 * WB_LD; u += 256) Xs[WB_BK * WB_LD + u] = (__bf16)0.f;
 
+  const bool do_bias = a.dbias != nullptr && ci0 == 0 && tid < TILE;
+  float bsum = 0.f;
   f32x4 dreg[D_IT], xreg[X_IT];
 #define DX_WG_LOAD(B_, NC_)                                                                                                   \
   {                                                                                                                           \
@@ -479,6 +490,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBf16Args 
     c += a.ksplit;
     while (c < total && !live(c, b, nc)) c += a.ksplit;
     if (c < total) DX_WG_LOAD(b, nc);
+    if (do_bias) {
+#pragma unroll 8
+      for (int k = 0; k < WB_BK; ++k) bsum += (float)Ds[k * WB_LD + tid];
+    }
 #pragma unroll
     for (int ks = 0; ks < WB_BK / 32; ++ks) {
       bf16x8 df[4];
@@ -512,6 +527,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBf16Args 
           if (co < a.Cout && acc[t][i][j][e] != 0.f) atomicAdd(&a.G[((size_t)t * a.Cout + co) * a.Cin + ci], acc[t][i][j][e]);
         }
       }
+  if (do_bias && co0 + tid < a.Cout && bsum != 0.f) atomicAdd(&a.dbias[co0 + tid], bsum);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -665,7 +681,7 @@ int dx_conv_gemm(const void* Xv, int ldx, const void* Wp, const float* bias, voi
 // G[taps][Cout][Cin] (fp32, caller-zeroed) += dY^T * shift(X); then dx_unpack_wgrad moves it to (Cout, Cin, taps).
 int dx_conv_wgrad(const void* dY, int ldy, const void* X, int ldx, float* G,
                   int B, int N, int Cin, int Cout, int taps, const int* lens, int skip_halo,
-                  int bf16, int dy_bf16, int x_bf16, void* stream) {
+                  int bf16, int dy_bf16, int x_bf16, float* dbias, void* stream) {
   DX_REQUIRE(dY && X && G, "dx_conv_wgrad: null pointer");
   DX_REQUIRE(bf16 || !(dy_bf16 || x_bf16), "dx_conv_wgrad: bf16 storage needs bf16 operand mode");
   const bool bf16_ok = (Cin % 8) == 0 && (ldx % 8) == 0 && (Cout % 8) == 0 && (ldy % 8) == 0;
@@ -677,7 +693,7 @@ int dx_conv_wgrad(const void* dY, int ldy, const void* X, int ldx, float* G,
     const int tiles = dx_cdiv(Cout, TILE) * dx_cdiv(Cin, 64);
     const int total_chunks = B * dx_cdiv(N, WB_BK);
     const int ksplit = std::max(1, std::min(total_chunks, dx_cdiv(768, tiles)));
-    WgradBf16Args a{dY, ldy, dy_bf16, X, ldx, x_bf16, G, B, N, Cin, Cout, ksplit, lens, skip_halo};
+    WgradBf16Args a{dY, ldy, dy_bf16, X, ldx, x_bf16, G, B, N, Cin, Cout, ksplit, lens, skip_halo, dbias};
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(tiles, 1, ksplit);
     dx_prof_begin(DX_PROF_WGRAD_GEMM, s);
@@ -699,7 +715,7 @@ int dx_conv_wgrad(const void* dY, int ldy, const void* X, int ldx, float* G,
   const int tiles = dx_cdiv(Cout, TILE) * dx_cdiv(Cin, TILE);
   const int total_chunks = B * dx_cdiv(N, WG_BK);
   int ksplit = std::max(1, std::min(total_chunks, dx_cdiv(1024, tiles * taps)));
-  WgradArgs a{(const float*)dY, ldy, (const float*)X, ldx, G, B, N, Cin, Cout, ksplit, lens, skip_halo};
+  WgradArgs a{(const float*)dY, ldy, (const float*)X, ldx, G, B, N, Cin, Cout, ksplit, lens, skip_halo, dbias};
   hipStream_t s = (hipStream_t)stream;
   dx_prof_begin(DX_PROF_WGRAD_GEMM, s);
   if (taps == 3) hipLaunchKernelGGL(wgrad_kernel<3>, dim3(tiles, taps, ksplit), dim3(256), 0, s, a);

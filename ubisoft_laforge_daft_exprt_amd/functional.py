@@ -59,8 +59,7 @@ class LinearFn(torch.autograd.Function):
             dy = ops.mask_rows(dy, ctx.lens)
         if ctx.relu:
             dy = ops.relu_bwd(dy, y)
-        dw = ops.conv_wgrad(dy, x2, ctx.pack)
-        db = ops.colsum(dy)
+        dw, db = ops.conv_wgrad(dy, x2, ctx.pack)
         dx = None
         if ctx.need_dx:
             dx = ops.conv_gemm(dy, ctx.pack, None, transpose=True, out_scale=ctx.grad_scale).view(ctx.xshape)
@@ -104,8 +103,8 @@ class PaddedLinearFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         dyp = torch.zeros(dy.shape[0], ctx.pack.cout, dtype=dy.dtype, device=dy.device)
         dyp[:, :ctx.cout].copy_(dy)
-        dw = ops.conv_wgrad(dyp, x, ctx.pack)[:ctx.cout]
-        db = ops.colsum(dyp)[:ctx.cout]
+        dw, db = ops.conv_wgrad(dyp, x, ctx.pack)
+        dw, db = dw[:ctx.cout], db[:ctx.cout]
         dx = ops.conv_gemm(dyp, ctx.pack, None, transpose=True)
         return dx, dw, db, None
 
@@ -141,25 +140,25 @@ class FFTBlockFn(torch.autograd.Function):
         lens, packs = ctx.lens, ctx.packs
         p_attn, p_conv, s_attn, s_ln1, s_ln2 = ctx.drop
         dy2 = dy2.contiguous()
-        dz2, da2, dln2_w, dln2_b, dfilm = ops.ln_bwd(dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, lens.i32,
-                                                      want_da=p_conv > 0, seed_pre=s_ln2, p_pre=p_conv)
-        dff = da2 if da2 is not None else dz2
         L = lens.i32
-        dc2_w = ops.conv_wgrad(dff, h, packs['c2'], L, 0)
-        dc2_b = ops.colsum(dff)
+        B, _, D = x.shape
+        Fc = h.shape[2]
+        pad = ops.ZeroArena.padded
+        arena = ops.ZeroArena(x.device, 6 * pad(D) + pad(B * 2 * D) + 2 * pad(3 * D * Fc) + pad(Fc) + pad(D * D) + pad(3 * D * D) + pad(3 * D) + 64)
+        dz2, da2, dln2_w, dln2_b, dfilm = ops.ln_bwd(dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, L,
+                                                      want_da=p_conv > 0, seed_pre=s_ln2, p_pre=p_conv, arena=arena)
+        dff = da2 if da2 is not None else dz2
+        dc2_w, dc2_b = ops.conv_wgrad(dff, h, packs['c2'], L, 0, arena=arena)
         dh = ops.conv_gemm(dff, packs['c2'], None, transpose=True, relu_aux=h, lens=L, halo=1, out_dtype=h.dtype)
-        dc1_w = ops.conv_wgrad(dh, y1, packs['c1'], L, 1)
-        dc1_b = ops.colsum(dh)
+        dc1_w, dc1_b = ops.conv_wgrad(dh, y1, packs['c1'], L, 1, arena=arena)
         dy1 = ops.conv_gemm(dh, packs['c1'], None, transpose=True, out=dz2, accumulate=True, lens=L, halo=0)  # + residual branch
-        dz1, da1, dln1_w, dln1_b, _ = ops.ln_bwd(dy1, z1, mean1, rstd1, ln1_w, ln1_b, None, lens.i32,
-                                                  want_da=p_attn > 0, seed_pre=s_ln1, p_pre=p_attn)
+        dz1, da1, dln1_w, dln1_b, _ = ops.ln_bwd(dy1, z1, mean1, rstd1, ln1_w, ln1_b, None, L,
+                                                  want_da=p_attn > 0, seed_pre=s_ln1, p_pre=p_attn, arena=arena)
         dproj = da1 if da1 is not None else dz1
-        dout_w = ops.conv_wgrad(dproj, att, packs['out'], L, 0)
-        dout_b = ops.colsum(dproj)
+        dout_w, dout_b = ops.conv_wgrad(dproj, att, packs['out'], L, 0, arena=arena)
         datt = ops.conv_gemm(dproj, packs['out'], None, transpose=True, lens=L, halo=0)
-        dqkv = ops.attention_bwd(qkv, att, datt, lse, lens.i32, ctx.heads, s_attn, p_attn)
-        din_w = ops.conv_wgrad(dqkv, x, packs['in'], L, 0)
-        din_b = ops.colsum(dqkv)
+        dqkv = ops.attention_bwd(qkv, att, datt, lse, L, ctx.heads, s_attn, p_attn)
+        din_w, din_b = ops.conv_wgrad(dqkv, x, packs['in'], L, 0, arena=arena)
         dx = ops.conv_gemm(dqkv, packs['in'], None, transpose=True, out=dz1, accumulate=True, lens=L, halo=0)  # + residual branch
         return (dx, dfilm, None, None, None, None,
                 din_w, din_b, dout_w, dout_b, dln1_w, dln1_b, dc1_w, dc1_b, dc2_w, dc2_b, dln2_w, dln2_b)
@@ -196,16 +195,13 @@ class AccentFrontFn(torch.autograd.Function):
         dwe, dbe, dwp, dbp = ops.scalar_conv_wgrad(dout, energy, pitch, lens.i32)
         dz2, _, dl2_w, dl2_b, _ = ops.ln_bwd(dout, h2, m2, r2, l2_w, l2_b, None, None, relu_mask=True, seed_post=seeds[2], p_post=p)
         L = lens.i32
-        dc2_w = ops.conv_wgrad(dz2, y1, packs['p2'], L, 0)
-        dc2_b = ops.colsum(dz2)
+        dc2_w, dc2_b = ops.conv_wgrad(dz2, y1, packs['p2'], L, 0)
         dy1 = ops.conv_gemm(dz2, packs['p2'], None, transpose=True, lens=L, halo=1)
         dz1, _, dl1_w, dl1_b, _ = ops.ln_bwd(dy1, h1, m1, r1, l1_w, l1_b, None, None, relu_mask=True, seed_post=seeds[1], p_post=p)
-        dc1_w = ops.conv_wgrad(dz1, y0, packs['p1'], L, 1)
-        dc1_b = ops.colsum(dz1)
+        dc1_w, dc1_b = ops.conv_wgrad(dz1, y0, packs['p1'], L, 1)
         dy0 = ops.conv_gemm(dz1, packs['p1'], None, transpose=True, lens=L, halo=2)
         dz0, _, dl0_w, dl0_b, _ = ops.ln_bwd(dy0, h0, m0, r0, l0_w, l0_b, None, None, relu_mask=True, seed_post=seeds[0], p_post=p)
-        dc0_w = ops.conv_wgrad(dz0, x0, packs['p0'], L, 2)
-        dc0_b = ops.colsum(dz0)
+        dc0_w, dc0_b = ops.conv_wgrad(dz0, x0, packs['p0'], L, 2)
         return (None, None, None, None, None, None, None, None,
                 dc0_w, dc0_b, dl0_w, dl0_b, dc1_w, dc1_b, dl1_w, dl1_b, dc2_w, dc2_b, dl2_w, dl2_b, dwe, dbe, dwp, dbp)
 
@@ -293,7 +289,6 @@ class MelProjectionFn(torch.autograd.Function):
     def backward(ctx, dmel):
         (x,) = ctx.saved_tensors
         d_cl = ops.mask_rows(ops.transpose(dmel.contiguous()), ctx.lens.i32)
-        dw = ops.conv_wgrad(d_cl, x, ctx.pack, ctx.lens.i32, 0)
-        db = ops.colsum(d_cl)
+        dw, db = ops.conv_wgrad(d_cl, x, ctx.pack, ctx.lens.i32, 0)
         dx = ops.conv_gemm(d_cl, ctx.pack, None, transpose=True, lens=ctx.lens.i32, halo=0)
         return dx, dw, db, None, None

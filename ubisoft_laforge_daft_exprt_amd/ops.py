@@ -127,19 +127,48 @@ def conv_gemm(x, pack: PackedWeight, bias=None, *, transpose=False, relu=False, 
     return out
 
 
-def conv_wgrad(dy, x, pack: PackedWeight, lens=None, halo=-1):
-    """Gradient w.r.t. the (Cout, Cin[, taps]) parameter, in the parameter's own layout."""
+class ZeroArena:
+    """One zero-filled buffer handed out in 16-byte aligned slices: the many small accumulators (atomic targets) of one
+    backward call cost a single memset launch instead of one each."""
+
+    def __init__(self, device, n_floats):
+        self.buf = torch.zeros(int(n_floats), dtype=torch.float32, device=device)
+        self.off = 0
+
+    @staticmethod
+    def padded(n):
+        return (int(n) + 3) // 4 * 4
+
+    def take(self, *shape):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if self.off + n > self.buf.numel():
+            return torch.zeros(*shape, dtype=torch.float32, device=self.buf.device)
+        out = self.buf[self.off:self.off + n].view(*shape)
+        self.off += self.padded(n)
+        return out
+
+
+def _zeros(arena, *shape, device=None):
+    return arena.take(*shape) if arena is not None else torch.zeros(*shape, dtype=torch.float32, device=device)
+
+
+def conv_wgrad(dy, x, pack: PackedWeight, lens=None, halo=-1, bias=True, arena=None):
+    """(dW, db): gradient w.r.t. the (Cout, Cin[, taps]) parameter in its own layout, and the bias gradient (column sums of
+    dY, accumulated by the same launch)."""
     B_, N_ = (1, x.shape[0]) if x.dim() == 2 else (x.shape[0], x.shape[1])
-    g = torch.zeros(pack.taps * pack.cout * pack.cin, dtype=torch.float32, device=x.device)
+    g = _zeros(arena, pack.taps * pack.cout * pack.cin, device=x.device)
+    db = _zeros(arena, pack.cout, device=x.device) if bias else None
     if _LAUNCH_LOG[0] is not None:
         _LAUNCH_LOG[0].append(('wgrad', B_ * N_, N_, pack.cin, pack.cout, pack.taps))
     lib().dx_conv_wgrad(_p(dy), _rows(dy), _p(x), _rows(x), _p(g), B_, N_, pack.cin, pack.cout, pack.taps, _p(lens), int(halo),
-                        _PRECISION['bf16'], _is_bf16(dy), _is_bf16(x), _stream())
+                        _PRECISION['bf16'], _is_bf16(dy), _is_bf16(x), _p(db), _stream())
     if pack.taps == 1:
-        return g.view(pack.weight.shape)
+        return g.view(pack.weight.shape), db
     grad = torch.empty(pack.weight.shape, dtype=torch.float32, device=x.device)
     lib().dx_unpack_wgrad(_p(g), _p(grad), pack.cout, pack.cin, pack.taps, 0, _stream())
-    return grad
+    return grad, db
 
 
 def colsum(x, C=None):
@@ -180,14 +209,15 @@ def ln_fwd(a, res, w, b, film, lens, *, seed_pre=0, p_pre=0.0, seed_post=0, p_po
     return y, mean, rstd
 
 
-def ln_bwd(dy, z, mean, rstd, w, b, film, lens, *, relu_mask=False, want_da=False, seed_pre=0, p_pre=0.0, seed_post=0, p_post=0.0):
+def ln_bwd(dy, z, mean, rstd, w, b, film, lens, *, relu_mask=False, want_da=False, seed_pre=0, p_pre=0.0, seed_post=0, p_post=0.0,
+           arena=None):
     """Returns (dz, da or None, dw, db, dfilm or None)."""
     B, N, C = z.shape
     dz = torch.empty_like(z)
     da = torch.empty_like(z) if want_da else None
-    dw = torch.zeros(C, dtype=torch.float32, device=z.device)
-    db = torch.zeros(C, dtype=torch.float32, device=z.device)
-    dfilm = torch.zeros(B, 2 * C, dtype=torch.float32, device=z.device) if film is not None else None
+    dw = _zeros(arena, C, device=z.device)
+    db = _zeros(arena, C, device=z.device)
+    dfilm = _zeros(arena, B, 2 * C, device=z.device) if film is not None else None
     lib().dx_ln_bwd(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(film), 0 if film is None else film.stride(0), _p(lens),
                     _p(dz), _p(da), _p(dw), _p(db), _p(dfilm), 2 * C, B, N, C, int(relu_mask),
                     seed_pre, float(p_pre), seed_post, float(p_post), _stream())
