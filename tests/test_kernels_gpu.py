@@ -143,24 +143,42 @@ def ref_attention(qkv, lens, heads, keep=None, p=0.0):
     return ctx * valid
 
 
+@pytest.mark.parametrize('precision,tol_f,tol_b', [('f32', 3e-6, 1e-5), ('bf16', 2e-2, 3e-2)])
 @pytest.mark.parametrize('B,N,lens', [(2, 64, [64, 33]), (3, 150, [150, 149, 7]), (1, 257, [257])])
-def test_attention_forward_backward(ops, B, N, lens):
+def test_attention_forward_backward(ops, B, N, lens, precision, tol_f, tol_b):
+    ops.set_precision(precision)
+    try:
+        _attention_forward_backward(ops, B, N, lens, tol_f, tol_b)
+    finally:
+        ops.set_precision('f32')
+
+
+def _attention_forward_backward(ops, B, N, lens, tol_f, tol_b):
     heads = 2
     qkv = randn(B, N, 384, seed=1).requires_grad_(True)
     ln = lens_tensor(lens)
     ctx, lse = ops.attention_fwd(qkv.detach(), ln, heads, 0, 0.0)
     ref = ref_attention(qkv, ln.long(), heads)
-    assert rel_err(ctx, ref) < 3e-6
+    assert rel_err(ctx, ref) < tol_f
     dctx = randn(B, N, 128, seed=2)
     valid = (torch.arange(N, device=DEV)[None, :] < ln[:, None])[:, :, None].float()
     dctx = dctx * valid                                    # the model never sends gradient into padded queries
     ref.backward(dctx)
     dqkv = ops.attention_bwd(qkv.detach(), ctx, dctx, lse, ln, heads, 0, 0.0)
-    assert rel_err(dqkv, qkv.grad) < 1e-5
+    assert rel_err(dqkv, qkv.grad) < tol_b
     assert torch.isfinite(dqkv).all()
 
 
-def test_attention_dropout_mask_consistency(ops):
+@pytest.mark.parametrize('precision', ['f32', 'bf16'])
+def test_attention_dropout_mask_consistency(ops, precision):
+    ops.set_precision(precision)
+    try:
+        _attention_dropout_mask_consistency(ops, 3e-6 if precision == 'f32' else 2e-2, 1e-5 if precision == 'f32' else 3e-2)
+    finally:
+        ops.set_precision('f32')
+
+
+def _attention_dropout_mask_consistency(ops, tol_f, tol_b):
     """q = k = 0 and one-hot V make ctx[q][key] = keep[q,key] / (len (1-p)): the mask is observable, so the backward's
     regenerated mask can be checked against the forward's."""
     B, N, heads, p = 2, 64, 2, 0.25
@@ -188,12 +206,12 @@ def test_attention_dropout_mask_consistency(ops):
     qkv_r = randn(B, N, 384, seed=5).requires_grad_(True)
     ctx_r, lse_r = ops.attention_fwd(qkv_r.detach(), ln, heads, seed, p)
     ref = ref_attention(qkv_r, ln.long(), heads, keep=keep, p=p)
-    assert rel_err(ctx_r, ref) < 3e-6
+    assert rel_err(ctx_r, ref) < tol_f
     valid = (torch.arange(N, device=DEV)[None, :] < ln[:, None])[:, :, None].float()
     dctx = randn(B, N, 128, seed=6) * valid
     ref.backward(dctx)
     dqkv = ops.attention_bwd(qkv_r.detach(), ctx_r, dctx, lse_r, ln, heads, seed, p)
-    assert rel_err(dqkv, qkv_r.grad) < 1e-5
+    assert rel_err(dqkv, qkv_r.grad) < tol_b
 
 
 @pytest.mark.parametrize('C', [128, 1024])

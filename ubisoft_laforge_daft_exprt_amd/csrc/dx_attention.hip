@@ -362,6 +362,317 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
   }
 }
 
+
+// =================================================================================================
+// bf16 MFMA variants (bf16 operand mode): K/V (or Q/dO) tiles live in LDS as bf16 [64][64] with 128-byte rows and XOR-swizzled
+// 16-byte slots.  Row-wise fragments are one ds_read_b128; the transposed fragments of V^T / K^T / dO^T / Q^T come from
+// ds_read_b64_tr_b16 (a 16-lane group reads a 4-row x 16-column block and every lane receives one column), so two 16x16 fp32
+// score tiles (32 keys) feed one v_mfma_f32_16x16x32_bf16 of the second product without any LDS round trip for P or dS.
+// Softmax statistics, exp and accumulation stay fp32.
+// =================================================================================================
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ int sw_off(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
+
+// stage rows [r0, r0+64) x 64 fp32 columns (from col0) as bf16 into the swizzled image; rows >= N are zero
+__device__ __forceinline__ void stage_tile_bf16(unsigned char* dst, const float* base, int ld, int col0, int r0, int N, int tid, float scale) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int u = tid + it * 256;
+    const int row = u >> 4, q = u & 15;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r0 + row < N) v = *reinterpret_cast<const float4*>(base + (size_t)(r0 + row) * ld + col0 + q * 4);
+    bf16x4 h;
+    h[0] = (__bf16)(v.x * scale); h[1] = (__bf16)(v.y * scale); h[2] = (__bf16)(v.z * scale); h[3] = (__bf16)(v.w * scale);
+    *reinterpret_cast<uint2*>(dst + sw_off(row, q >> 1) + ((q & 1) << 3)) = __builtin_bit_cast(uint2, h);
+  }
+}
+
+// row fragment: 8 consecutive columns (32*ks + 8*g ..) of row `row`
+__device__ __forceinline__ bf16x8 row_frag(const unsigned char* tile, int row, int ks, int g) {
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(tile + sw_off(row, ks * 4 + g)));
+}
+
+// transposed half fragment: rows row0..row0+3 (row0 already includes the lane group's 4*g), columns col0..col0+15;
+// lane (lane & 15) receives column col0 + (lane & 15), rows row0..row0+3
+__device__ __forceinline__ s16x4 tr_half(const unsigned char* tile, int row0, int col0, int lane) {
+  const int li = lane & 15, q = li >> 2, p = li & 3;
+  const unsigned char* addr = tile + sw_off(row0 + q, (col0 >> 3) + (p >> 1)) + ((p & 1) << 3);
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(addr));
+}
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* tile, int rowA, int rowB, int col0, int lane) {
+  const s16x4 lo = tr_half(tile, rowA, col0, lane), hi = tr_half(tile, rowB, col0, lane);
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {
+  bf16x8 h;
+  h[0] = (__bf16)a[0]; h[1] = (__bf16)a[1]; h[2] = (__bf16)a[2]; h[3] = (__bf16)a[3];
+  h[4] = (__bf16)b[0]; h[5] = (__bf16)b[1]; h[6] = (__bf16)b[2]; h[7] = (__bf16)b[3];
+  return h;
+}
+// 8 consecutive fp32 values of a global row -> bf16x8 (scaled)
+__device__ __forceinline__ bf16x8 load_row8(const float* p, float scale) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  bf16x8 h;
+  h[0] = (__bf16)(a.x * scale); h[1] = (__bf16)(a.y * scale); h[2] = (__bf16)(a.z * scale); h[3] = (__bf16)(a.w * scale);
+  h[4] = (__bf16)(b.x * scale); h[5] = (__bf16)(b.y * scale); h[6] = (__bf16)(b.z * scale); h[7] = (__bf16)(b.w * scale);
+  return h;
+}
+#define DX_MFMA_BF16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A), (B), (C), 0, 0, 0)
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * 128];
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int len = a.lens[b];
+  const float* base = a.qkv + (size_t)b * a.N * a.ld;
+  const int qrow = q0 + wave * 16 + r;
+  float* out = a.ctx + ((size_t)b * a.N + qrow) * a.ldc + h * HD;
+  if (q0 >= len) {
+    if (qrow < a.N) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<float4*>(out + dt * 16 + g * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g == 0) a.lse[((size_t)b * a.H + h) * a.N + qrow] = 0.f;
+    }
+    return;
+  }
+  const int qload = min(qrow, a.N - 1);
+  bf16x8 qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) qf[ks] = load_row8(base + (size_t)qload * a.ld + h * HD + ks * 32 + g * 8, QSCALE);
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const int bh = b * a.H + h;
+  const int ntiles = (len + 63) / 64;
+  for (int kt0 = 0; kt0 < ntiles; ++kt0) {
+    const int kbase = kt0 * 64;
+    __syncthreads();
+    stage_tile_bf16(Ks, base, a.ld, a.D + h * HD, kbase, a.N, tid, 1.f);
+    stage_tile_bf16(Vs, base, a.ld, 2 * a.D + h * HD, kbase, a.N, tid, 1.f);
+    __syncthreads();
+    f32x4 st[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) acc = DX_MFMA_BF16(row_frag(Ks, kt * 16 + r, ks, g), qf[ks], acc);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (kbase + kt * 16 + g * 4 + e >= len) acc[e] = -INFINITY;
+        mx = fmaxf(mx, acc[e]);
+      }
+      st[kt] = acc;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = expf(m_run - m_new);
+    float ls = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      float keep[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.thresh) dx_dropout_scale4(a.seed, drop_index(bh, a.N, qrow, kbase + kt * 16 + g * 4), a.thresh, a.inv_keep, keep);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p = expf(st[kt][e] - m_new);
+        ls += p;
+        st[kt][e] = p * keep[e];
+      }
+    }
+    ls += __shfl_xor(ls, 16, 64);
+    ls += __shfl_xor(ls, 32, 64);
+    l_run = l_run * alpha + ls;
+    m_run = m_new;
+    const bf16x8 p01 = pack_pair(st[0], st[1]), p23 = pack_pair(st[2], st[3]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4 acc = o[dt];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] *= alpha;
+      acc = DX_MFMA_BF16(tr_pair(Vs, 0 + g * 4, 16 + g * 4, dt * 16, lane), p01, acc);
+      acc = DX_MFMA_BF16(tr_pair(Vs, 32 + g * 4, 48 + g * 4, dt * 16, lane), p23, acc);
+      o[dt] = acc;
+    }
+  }
+  if (qrow < a.N) {
+    const bool valid = qrow < len;
+    const float inv = valid ? 1.f / l_run : 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      *reinterpret_cast<float4*>(out + dt * 16 + g * 4) = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+    if (g == 0) a.lse[((size_t)b * a.H + h) * a.N + qrow] = valid ? m_run + logf(l_run) : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * 128];
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int len = a.lens[b];
+  const float* base = a.qkv + (size_t)b * a.N * a.ld;
+  const int qrow = q0 + wave * 16 + r;
+  float* out = a.dqkv + ((size_t)b * a.N + qrow) * a.ldg + h * HD;
+  if (q0 >= len) {
+    if (qrow < a.N) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<float4*>(out + dt * 16 + g * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
+  const int qload = min(qrow, a.N - 1);
+  const int bh = b * a.H + h;
+  bf16x8 qf[2], gf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    qf[ks] = load_row8(base + (size_t)qload * a.ld + h * HD + ks * 32 + g * 8, QSCALE);
+    gf[ks] = load_row8(a.dctx + ((size_t)b * a.N + qload) * a.ldc + h * HD + ks * 32 + g * 8, 1.f);
+  }
+  const float lse_q = a.lse[(size_t)bh * a.N + qload];
+  const float delta_q = a.delta[(size_t)bh * a.N + qload];
+  f32x4 dq[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (len + 63) / 64;
+  for (int kt0 = 0; kt0 < ntiles; ++kt0) {
+    const int kbase = kt0 * 64;
+    __syncthreads();
+    stage_tile_bf16(Ks, base, a.ld, a.D + h * HD, kbase, a.N, tid, 1.f);
+    stage_tile_bf16(Vs, base, a.ld, 2 * a.D + h * HD, kbase, a.N, tid, 1.f);
+    __syncthreads();
+    f32x4 ds[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        s = DX_MFMA_BF16(row_frag(Ks, kt * 16 + r, ks, g), qf[ks], s);
+        dp = DX_MFMA_BF16(row_frag(Vs, kt * 16 + r, ks, g), gf[ks], dp);
+      }
+      float keep[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.thresh) dx_dropout_scale4(a.seed, drop_index(bh, a.N, qrow, kbase + kt * 16 + g * 4), a.thresh, a.inv_keep, keep);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool masked = kbase + kt * 16 + g * 4 + e >= len;
+        const float p = masked ? 0.f : expf(s[e] - lse_q);
+        s[e] = p * (dp[e] * keep[e] - delta_q) * QSCALE;
+      }
+      ds[kt] = s;
+    }
+    const bf16x8 d01 = pack_pair(ds[0], ds[1]), d23 = pack_pair(ds[2], ds[3]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4 acc = dq[dt];
+      acc = DX_MFMA_BF16(tr_pair(Ks, 0 + g * 4, 16 + g * 4, dt * 16, lane), d01, acc);
+      acc = DX_MFMA_BF16(tr_pair(Ks, 32 + g * 4, 48 + g * 4, dt * 16, lane), d23, acc);
+      dq[dt] = acc;
+    }
+  }
+  if (qrow < a.N) {
+    const float z = qrow < len ? 1.f : 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      *reinterpret_cast<float4*>(out + dt * 16 + g * 4) = make_float4(dq[dt][0] * z, dq[dt][1] * z, dq[dt][2] * z, dq[dt][3] * z);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char Qs[64 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char Gs[64 * 128];
+  __shared__ float lse_s[64], delta_s[64];
+  const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int len = a.lens[b];
+  const float* base = a.qkv + (size_t)b * a.N * a.ld;
+  const float* gbase = a.dctx + (size_t)b * a.N * a.ldc;
+  const int krow = k0 + wave * 16 + r;
+  float* outk = a.dqkv + ((size_t)b * a.N + krow) * a.ldg + a.D + h * HD;
+  float* outv = a.dqkv + ((size_t)b * a.N + krow) * a.ldg + 2 * a.D + h * HD;
+  if (k0 >= len) {
+    if (krow < a.N) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        *reinterpret_cast<float4*>(outk + dt * 16 + g * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(outv + dt * 16 + g * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    return;
+  }
+  const int kload = min(krow, a.N - 1);
+  const bool key_valid = krow < len;
+  const int bh = b * a.H + h;
+  bf16x8 kf[2], vf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    kf[ks] = load_row8(base + (size_t)kload * a.ld + a.D + h * HD + ks * 32 + g * 8, QSCALE);
+    vf[ks] = load_row8(base + (size_t)kload * a.ld + 2 * a.D + h * HD + ks * 32 + g * 8, 1.f);
+  }
+  f32x4 dk[4], dv[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const int ntiles = (len + 63) / 64;
+  for (int qt0 = 0; qt0 < ntiles; ++qt0) {
+    const int qbase = qt0 * 64;
+    __syncthreads();
+    stage_tile_bf16(Qs, base, a.ld, h * HD, qbase, a.N, tid, 1.f);
+    stage_tile_bf16(Gs, gbase, a.ldc, h * HD, qbase, a.N, tid, 1.f);
+    if (tid < 64) {
+      const int q = qbase + tid;
+      lse_s[tid] = q < a.N ? a.lse[(size_t)bh * a.N + q] : 0.f;
+      delta_s[tid] = q < a.N ? a.delta[(size_t)bh * a.N + q] : 0.f;
+    }
+    __syncthreads();
+    f32x4 pd[4], ds[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        s = DX_MFMA_BF16(row_frag(Qs, qt * 16 + r, ks, g), kf[ks], s);
+        dp = DX_MFMA_BF16(row_frag(Gs, qt * 16 + r, ks, g), vf[ks], dp);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ql = qt * 16 + g * 4 + e, q = qbase + ql;
+        const bool live = key_valid && q < len;
+        const float p = live ? expf(s[e] - lse_s[ql]) : 0.f;
+        float keep = 1.f;
+        if (a.thresh) keep = dx_dropout_scale(a.seed, drop_index(bh, a.N, q, krow), a.thresh, a.inv_keep);
+        pd[qt][e] = p * keep;
+        ds[qt][e] = p * (dp[e] * keep - delta_s[ql]) * QSCALE;
+      }
+    }
+    const bf16x8 p01 = pack_pair(pd[0], pd[1]), p23 = pack_pair(pd[2], pd[3]);
+    const bf16x8 d01 = pack_pair(ds[0], ds[1]), d23 = pack_pair(ds[2], ds[3]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4 accv = dv[dt], acck = dk[dt];
+      accv = DX_MFMA_BF16(tr_pair(Gs, 0 + g * 4, 16 + g * 4, dt * 16, lane), p01, accv);
+      accv = DX_MFMA_BF16(tr_pair(Gs, 32 + g * 4, 48 + g * 4, dt * 16, lane), p23, accv);
+      acck = DX_MFMA_BF16(tr_pair(Qs, 0 + g * 4, 16 + g * 4, dt * 16, lane), d01, acck);
+      acck = DX_MFMA_BF16(tr_pair(Qs, 32 + g * 4, 48 + g * 4, dt * 16, lane), d23, acck);
+      dv[dt] = accv; dk[dt] = acck;
+    }
+  }
+  if (krow < a.N) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      *reinterpret_cast<float4*>(outk + dt * 16 + g * 4) = make_float4(dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]);
+      *reinterpret_cast<float4*>(outv + dt * 16 + g * 4) = make_float4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
+    }
+  }
+}
+#undef DX_MFMA_BF16
+
 int check_common(const char* who, const void* qkv, int ld, int B, int N, int H, int D) {
   DX_REQUIRE(qkv != nullptr, "%s: null pointer", who);
   DX_REQUIRE(B > 0 && N > 0 && H > 0 && D == H * HD, "%s: head dim must be 64 (D=%d, H=%d)", who, D, H);
@@ -375,14 +686,15 @@ int check_common(const char* who, const void* qkv, int ld, int B, int N, int H, 
 extern "C" {
 
 int dx_attention_fwd(const float* qkv, int ld, const int* lens, float* ctx, int ldc, float* lse,
-                     int B, int N, int H, int D, uint64_t seed, float p_drop, void* stream) {
+                     int B, int N, int H, int D, uint64_t seed, float p_drop, int bf16, void* stream) {
   if (int rc = check_common("dx_attention_fwd", qkv, ld, B, N, H, D)) return rc;
   DX_REQUIRE(lens && ctx && lse && ldc >= D && (ldc % 4) == 0 && ((uintptr_t)ctx % 16) == 0, "dx_attention_fwd: bad output arguments");
   DX_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "dx_attention_fwd: dropout p out of range");
   AttnArgs a{qkv, ld, lens, ctx, ldc, lse, B, N, H, D, seed, (uint32_t)lrintf(p_drop * 65536.f), 1.f / (1.f - p_drop)};
   hipStream_t s = (hipStream_t)stream;
   dx_prof_begin(DX_PROF_ATTN_FWD, s);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
+  if (bf16) hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(attn_fwd_kernel, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
   dx_prof_end(DX_PROF_ATTN_FWD, s);
   DX_LAUNCH_CHECK("dx_attention_fwd");
   return DX_OK;
@@ -390,7 +702,7 @@ int dx_attention_fwd(const float* qkv, int ld, const int* lens, float* ctx, int 
 
 // dqkv (all three thirds, every row) from dctx; `delta` is scratch [B][H][N]
 int dx_attention_bwd(const float* qkv, int ld, const float* ctx, const float* dctx, int ldc, const float* lse, float* delta,
-                     const int* lens, float* dqkv, int ldg, int B, int N, int H, int D, uint64_t seed, float p_drop, void* stream) {
+                     const int* lens, float* dqkv, int ldg, int B, int N, int H, int D, uint64_t seed, float p_drop, int bf16, void* stream) {
   if (int rc = check_common("dx_attention_bwd", qkv, ld, B, N, H, D)) return rc;
   DX_REQUIRE(ctx && dctx && lse && delta && lens && dqkv, "dx_attention_bwd: null pointer");
   DX_REQUIRE(ldc >= D && (ldc % 4) == 0 && ldg >= 3 * D && (ldg % 4) == 0, "dx_attention_bwd: bad leading dimensions");
@@ -401,8 +713,13 @@ int dx_attention_bwd(const float* qkv, int ld, const float* ctx, const float* dc
   hipLaunchKernelGGL(attn_delta_kernel, dim3((int)std::min<long>((items + 3) / 4, 8192)), dim3(256), 0, s, dctx, ctx, ldc, delta, B, N, H);
   AttnBwdArgs a{qkv, ld, dctx, ldc, lse, delta, lens, dqkv, ldg, B, N, H, D, seed, (uint32_t)lrintf(p_drop * 65536.f), 1.f / (1.f - p_drop)};
   dx_prof_begin(DX_PROF_ATTN_BWD, s);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
+  if (bf16) {
+    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
+  }
   dx_prof_end(DX_PROF_ATTN_BWD, s);
   DX_LAUNCH_CHECK("dx_attention_bwd");
   return DX_OK;

@@ -184,7 +184,7 @@ def attention_fwd(qkv, lens, heads, seed, p_drop):
     D = D3 // 3
     ctx = torch.empty(B, N, D, dtype=torch.float32, device=qkv.device)
     lse = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device)
-    lib().dx_attention_fwd(_p(qkv), _rows(qkv), _p(lens), _p(ctx), D, _p(lse), B, N, heads, D, seed, float(p_drop), _stream())
+    lib().dx_attention_fwd(_p(qkv), _rows(qkv), _p(lens), _p(ctx), D, _p(lse), B, N, heads, D, seed, float(p_drop), _PRECISION['bf16'], _stream())
     return ctx, lse
 
 
@@ -194,7 +194,7 @@ def attention_bwd(qkv, ctx, dctx, lse, lens, heads, seed, p_drop):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device)
     lib().dx_attention_bwd(_p(qkv), _rows(qkv), _p(ctx), _p(dctx), _rows(dctx), _p(lse), _p(delta), _p(lens), _p(dqkv), _rows(dqkv),
-                           B, N, heads, D, seed, float(p_drop), _stream())
+                           B, N, heads, D, seed, float(p_drop), _PRECISION['bf16'], _stream())
     return dqkv
 
 
