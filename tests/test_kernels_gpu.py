@@ -236,7 +236,8 @@ def test_layernorm_family(ops, C, use_film, use_res, use_mask):
     y, mean, rstd = ops.ln_fwd(a_k, None if res is None else res.detach(), w.detach(), b.detach(),
                                None if film is None else film.detach(), lens)
     assert rel_err(y, ref) < 3e-6
-    assert rel_err(a_k, z.detach()) < 1e-7                 # z written back in place
+    vmask = torch.ones(B, N, 1, device=DEV) if lens is None else (torch.arange(N, device=DEV)[None, :] < lens[:, None])[:, :, None].float()
+    assert rel_err(a_k * vmask, z.detach() * vmask) < 1e-7   # z written back in place (valid rows; padded rows are not computed)
     dy = randn(B, N, C, seed=6)
     ref.backward(dy)
     dz, da, dw, db, dfilm = ops.ln_bwd(dy, a_k, mean, rstd, w.detach(), b.detach(), None if film is None else film.detach(), lens)
@@ -254,9 +255,10 @@ def test_layernorm_dropout_and_relu_mask(ops):
     lens = lens_tensor([33, 20])
     a_k = a0.clone()
     y, mean, rstd = ops.ln_fwd(a_k, res, w, b, None, lens, seed_pre=77, p_pre=p)
-    keep = ((a_k - res) / a0 * (1 - p)).round()            # observable pre-dropout mask
+    vmask = (torch.arange(N, device=DEV)[None, :] < lens[:, None])[:, :, None]
+    keep = torch.where(vmask, ((a_k - res) / a0 * (1 - p)).round(), torch.ones_like(a0))   # observable pre-dropout mask (valid rows)
     assert set(keep.unique().tolist()) <= {0.0, 1.0}
-    assert abs(keep.mean().item() - (1 - p)) < 0.03
+    assert abs(keep[vmask.expand_as(keep)].mean().item() - (1 - p)) < 0.03
     a = a0.clone().requires_grad_(True)
     ref = F.layer_norm(a * keep / (1 - p) + res, (C,), w, b, 1e-5) * (torch.arange(N, device=DEV)[None, :] < lens[:, None])[:, :, None]
     assert rel_err(y, ref) < 3e-6

@@ -557,6 +557,34 @@ __global__ void pack_weights_kernel(const float* __restrict__ W, T* __restrict__
   }
 }
 
+// all layers of a model in ONE launch: blockIdx.y = layer, descriptors in device memory
+struct PackDesc {
+  const float* W; void* fwd; void* bwd;
+  int Cout, Cin, taps, CoutP_f, CinP_f, CinP_b, CoutP_b, pad;
+};
+template <typename T>
+__global__ void pack_weights_batched_kernel(const PackDesc* __restrict__ descs) {
+  const PackDesc d = descs[blockIdx.y];
+  T* fwd = reinterpret_cast<T*>(d.fwd);
+  T* bwd = reinterpret_cast<T*>(d.bwd);
+  const size_t nf = (size_t)d.taps * d.CoutP_f * d.CinP_f;
+  const size_t nb = bwd ? (size_t)d.taps * d.CinP_b * d.CoutP_b : 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nb; i += (size_t)gridDim.x * blockDim.x) {
+    if (i < nf) {
+      const int ci = (int)(i % d.CinP_f);
+      const int co = (int)((i / d.CinP_f) % d.CoutP_f);
+      const int tap = (int)(i / ((size_t)d.CinP_f * d.CoutP_f));
+      fwd[i] = (T)((co < d.Cout && ci < d.Cin) ? d.W[((size_t)co * d.Cin + ci) * d.taps + tap] : 0.f);
+    } else {
+      const size_t k = i - nf;
+      const int co = (int)(k % d.CoutP_b);
+      const int ci = (int)((k / d.CoutP_b) % d.CinP_b);
+      const int tap = (int)(k / ((size_t)d.CoutP_b * d.CinP_b));
+      bwd[k] = (T)((co < d.Cout && ci < d.Cin) ? d.W[((size_t)co * d.Cin + ci) * d.taps + (d.taps - 1 - tap)] : 0.f);
+    }
+  }
+}
+
 // grad[co][ci][tap] (+)= G[tap][co][ci]
 __global__ void unpack_wgrad_kernel(const float* __restrict__ G, float* __restrict__ grad, int Cout, int Cin, int taps, int accumulate) {
   const size_t n = (size_t)Cout * Cin * taps;
@@ -640,6 +668,17 @@ int dx_pack_weights(const float* W, void* fwd, void* bwd, int Cout, int Cin, int
   else
     hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, s, W, (float*)fwd, (float*)bwd, Cout, Cin, taps, d[0], d[1], d[2], d[3]);
   DX_LAUNCH_CHECK("dx_pack_weights");
+  return DX_OK;
+}
+
+// descs: device array of n records {W, fwd, bwd (8-byte pointers), Cout, Cin, taps, CoutP_f, CinP_f, CinP_b, CoutP_b, pad (int32)}
+int dx_pack_weights_batched(const void* descs, int n, int bf16, void* stream) {
+  DX_REQUIRE(descs && n > 0, "dx_pack_weights_batched: bad arguments");
+  static_assert(sizeof(PackDesc) == 56, "PackDesc layout is part of the ABI");
+  dim3 grid(64, n);
+  if (bf16) hipLaunchKernelGGL(pack_weights_batched_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs);
+  else hipLaunchKernelGGL(pack_weights_batched_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs);
+  DX_LAUNCH_CHECK("dx_pack_weights_batched");
   return DX_OK;
 }
 

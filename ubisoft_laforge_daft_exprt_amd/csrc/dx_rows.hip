@@ -73,6 +73,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
     const int b = (int)(row / a.N), n = (int)(row - (long)b * a.N);
     const bool valid = !a.lens || n < a.lens[b];
     float z[E];
+    if (!valid) {
+      // padded row: the output is zero by definition and nothing reads z / mean / rstd of it (the backward skips it too);
+      // keep them defined without touching the inputs
+#pragma unroll
+      for (int e = 0; e < E; ++e) z[e] = 0.f;
+      row_store<C>(a.y + row * C, lane, z);
+      if (a.thresh_pre || a.res) row_store<C>(a.a + row * C, lane, z);
+      if (lane == 0) { a.mean[row] = 0.f; a.rstd[row] = 0.f; }
+      continue;
+    }
     row_load<C>(a.a + row * C, lane, z);
     if (a.thresh_pre) {
 #pragma unroll

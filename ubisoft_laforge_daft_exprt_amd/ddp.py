@@ -20,7 +20,9 @@ import torch.distributed as dist
 
 
 class GradientReducer:
-    def __init__(self, module: torch.nn.Module, bucket_mb: float = 16.0, process_group=None):
+    def __init__(self, module: torch.nn.Module, bucket_mb: float = 16.0, process_group=None, grad_sink: bool = False):
+        """``grad_sink=True``: the HIP backward kernels accumulate straight into the bucket views (functional.set_grad_sink);
+        requires ``zero_grad()`` of THIS object before every backward."""
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -51,6 +53,9 @@ class GradientReducer:
         self.works = []
         self.hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
         self._avg = None
+        if grad_sink:
+            from . import functional
+            functional.set_grad_sink(True, self._on_grad)
 
     def _reduce_op(self):
         if self._avg is None:
@@ -84,3 +89,6 @@ class GradientReducer:
     def remove(self):
         for h in self.hooks:
             h.remove()
+        from . import functional
+        if functional._GRAD_SINK['hook'] == self._on_grad:
+            functional.set_grad_sink(False)

@@ -28,6 +28,36 @@ def next_seed() -> int:
     return (_seed_state.base + _seed_state.counter * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# gradient sink: when a trainer pre-allocates (and zeroes) ``param.grad`` -- as ddp.GradientReducer does with views into its
+# communication buckets -- the backward kernels accumulate straight into it (atomics / accumulate epilogues) and hand
+# autograd ``None``: no temporary gradient tensor, no ATen ``+=`` launch per parameter.  ``_GRAD_SINK['hook']`` is called
+# with the parameter once its gradient is complete (the reducer's bucket bookkeeping).
+# ----------------------------------------------------------------------------------------------------------------------
+_GRAD_SINK = {'enabled': False, 'hook': None}
+
+
+def set_grad_sink(enabled: bool, hook=None) -> None:
+    _GRAD_SINK['enabled'] = bool(enabled)
+    _GRAD_SINK['hook'] = hook if enabled else None
+
+
+def _sink(param):
+    if not _GRAD_SINK['enabled'] or param is None:
+        return None
+    g = param.grad
+    if g is None or not g.is_contiguous() or g.dtype != torch.float32:
+        return None
+    return g
+
+
+def _sunk(*params):
+    hook = _GRAD_SINK['hook']
+    if hook is not None:
+        for p in params:
+            hook(p)
+
+
 class Lengths:
     """Valid lengths of one axis of a padded batch: int32 on the device for the kernels, Python ints for shapes."""
 
@@ -145,21 +175,25 @@ class FFTBlockFn(torch.autograd.Function):
         Fc = h.shape[2]
         pad = ops.ZeroArena.padded
         arena = ops.ZeroArena(x.device, 6 * pad(D) + pad(B * 2 * D) + 2 * pad(3 * D * Fc) + pad(Fc) + pad(D * D) + pad(3 * D * D) + pad(3 * D) + 64)
-        dz2, da2, dln2_w, dln2_b, dfilm = ops.ln_bwd(dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, L,
-                                                      want_da=p_conv > 0, seed_pre=s_ln2, p_pre=p_conv, arena=arena)
+        P = packs.get('params', {})
+        sk = {k: _sink(v) for k, v in P.items()}
+        g = sk.get
+        dz2, da2, dln2_w, dln2_b, dfilm = ops.ln_bwd(dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, L, want_da=p_conv > 0, seed_pre=s_ln2,
+                                                      p_pre=p_conv, arena=arena, w_sink=g('ln2_w'), b_sink=g('ln2_b'))
         dff = da2 if da2 is not None else dz2
-        dc2_w, dc2_b = ops.conv_wgrad(dff, h, packs['c2'], L, 0, arena=arena)
+        dc2_w, dc2_b = ops.conv_wgrad(dff, h, packs['c2'], L, 0, arena=arena, w_sink=g('c2_w'), b_sink=g('c2_b'))
         dh = ops.conv_gemm(dff, packs['c2'], None, transpose=True, relu_aux=h, lens=L, halo=1, out_dtype=h.dtype)
-        dc1_w, dc1_b = ops.conv_wgrad(dh, y1, packs['c1'], L, 1, arena=arena)
+        dc1_w, dc1_b = ops.conv_wgrad(dh, y1, packs['c1'], L, 1, arena=arena, w_sink=g('c1_w'), b_sink=g('c1_b'))
         dy1 = ops.conv_gemm(dh, packs['c1'], None, transpose=True, out=dz2, accumulate=True, lens=L, halo=0)  # + residual branch
-        dz1, da1, dln1_w, dln1_b, _ = ops.ln_bwd(dy1, z1, mean1, rstd1, ln1_w, ln1_b, None, L,
-                                                  want_da=p_attn > 0, seed_pre=s_ln1, p_pre=p_attn, arena=arena)
+        dz1, da1, dln1_w, dln1_b, _ = ops.ln_bwd(dy1, z1, mean1, rstd1, ln1_w, ln1_b, None, L, want_da=p_attn > 0, seed_pre=s_ln1,
+                                                  p_pre=p_attn, arena=arena, w_sink=g('ln1_w'), b_sink=g('ln1_b'))
         dproj = da1 if da1 is not None else dz1
-        dout_w, dout_b = ops.conv_wgrad(dproj, att, packs['out'], L, 0, arena=arena)
+        dout_w, dout_b = ops.conv_wgrad(dproj, att, packs['out'], L, 0, arena=arena, w_sink=g('out_w'), b_sink=g('out_b'))
         datt = ops.conv_gemm(dproj, packs['out'], None, transpose=True, lens=L, halo=0)
         dqkv = ops.attention_bwd(qkv, att, datt, lse, L, ctx.heads, s_attn, p_attn)
-        din_w, din_b = ops.conv_wgrad(dqkv, x, packs['in'], L, 0, arena=arena)
+        din_w, din_b = ops.conv_wgrad(dqkv, x, packs['in'], L, 0, arena=arena, w_sink=g('in_w'), b_sink=g('in_b'))
         dx = ops.conv_gemm(dqkv, packs['in'], None, transpose=True, out=dz1, accumulate=True, lens=L, halo=0)  # + residual branch
+        _sunk(*[P[k] for k, v in sk.items() if v is not None])
         return (dx, dfilm, None, None, None, None,
                 din_w, din_b, dout_w, dout_b, dln1_w, dln1_b, dc1_w, dc1_b, dc2_w, dc2_b, dln2_w, dln2_b)
 
@@ -193,15 +227,22 @@ class AccentFrontFn(torch.autograd.Function):
         lens, packs, p, seeds = ctx.lens, ctx.packs, ctx.p, ctx.seeds
         dout = ops.mask_rows(dout.contiguous(), lens.i32)
         dwe, dbe, dwp, dbp = ops.scalar_conv_wgrad(dout, energy, pitch, lens.i32)
-        dz2, _, dl2_w, dl2_b, _ = ops.ln_bwd(dout, h2, m2, r2, l2_w, l2_b, None, None, relu_mask=True, seed_post=seeds[2], p_post=p)
         L = lens.i32
-        dc2_w, dc2_b = ops.conv_wgrad(dz2, y1, packs['p2'], L, 0)
+        P = packs.get('params', {})
+        sk = {k: _sink(v) for k, v in P.items()}
+        g = sk.get
+        dz2, _, dl2_w, dl2_b, _ = ops.ln_bwd(dout, h2, m2, r2, l2_w, l2_b, None, None, relu_mask=True, seed_post=seeds[2], p_post=p,
+                                              w_sink=g('l2_w'), b_sink=g('l2_b'))
+        dc2_w, dc2_b = ops.conv_wgrad(dz2, y1, packs['p2'], L, 0, w_sink=g('c2_w'), b_sink=g('c2_b'))
         dy1 = ops.conv_gemm(dz2, packs['p2'], None, transpose=True, lens=L, halo=1)
-        dz1, _, dl1_w, dl1_b, _ = ops.ln_bwd(dy1, h1, m1, r1, l1_w, l1_b, None, None, relu_mask=True, seed_post=seeds[1], p_post=p)
-        dc1_w, dc1_b = ops.conv_wgrad(dz1, y0, packs['p1'], L, 1)
+        dz1, _, dl1_w, dl1_b, _ = ops.ln_bwd(dy1, h1, m1, r1, l1_w, l1_b, None, None, relu_mask=True, seed_post=seeds[1], p_post=p,
+                                              w_sink=g('l1_w'), b_sink=g('l1_b'))
+        dc1_w, dc1_b = ops.conv_wgrad(dz1, y0, packs['p1'], L, 1, w_sink=g('c1_w'), b_sink=g('c1_b'))
         dy0 = ops.conv_gemm(dz1, packs['p1'], None, transpose=True, lens=L, halo=2)
-        dz0, _, dl0_w, dl0_b, _ = ops.ln_bwd(dy0, h0, m0, r0, l0_w, l0_b, None, None, relu_mask=True, seed_post=seeds[0], p_post=p)
-        dc0_w, dc0_b = ops.conv_wgrad(dz0, x0, packs['p0'], L, 2)
+        dz0, _, dl0_w, dl0_b, _ = ops.ln_bwd(dy0, h0, m0, r0, l0_w, l0_b, None, None, relu_mask=True, seed_post=seeds[0], p_post=p,
+                                              w_sink=g('l0_w'), b_sink=g('l0_b'))
+        dc0_w, dc0_b = ops.conv_wgrad(dz0, x0, packs['p0'], L, 2, w_sink=g('c0_w'), b_sink=g('c0_b'))
+        _sunk(*[P[k] for k, v in sk.items() if v is not None])
         return (None, None, None, None, None, None, None, None,
                 dc0_w, dc0_b, dl0_w, dl0_b, dc1_w, dc1_b, dl1_w, dl1_b, dc2_w, dc2_b, dl2_w, dl2_b, dwe, dbe, dwp, dbp)
 

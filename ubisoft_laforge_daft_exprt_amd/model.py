@@ -116,7 +116,10 @@ class FFTBlock(nn.Module):
     def forward(self, x, film_params, lens: Lengths):
         mha, ln1 = self.attention.multi_head_attention, self.attention.layer_norm
         c1, c2, ln2 = self.feed_forward.convs[0].conv, self.feed_forward.convs[2].conv, self.feed_forward.layer_norm
-        packs = {'in': mha.in_pack, 'out': mha.out_proj.pack, 'c1': c1.pack, 'c2': c2.pack}
+        packs = {'in': mha.in_pack, 'out': mha.out_proj.pack, 'c1': c1.pack, 'c2': c2.pack,
+                 'params': {'in_w': mha.in_proj_weight, 'in_b': mha.in_proj_bias, 'out_w': mha.out_proj.weight, 'out_b': mha.out_proj.bias,
+                            'ln1_w': ln1.weight, 'ln1_b': ln1.bias, 'c1_w': c1.weight, 'c1_b': c1.bias, 'c2_w': c2.weight, 'c2_b': c2.bias,
+                            'ln2_w': ln2.weight, 'ln2_b': ln2.bias}}
         return Fx.FFTBlockFn.apply(x, film_params, lens, packs, self.cfg, self.training,
                                    mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias,
                                    ln1.weight, ln1.bias, c1.weight, c1.bias, c2.weight, c2.bias, ln2.weight, ln2.bias)
@@ -166,7 +169,10 @@ class AccentEncoder(nn.Module):
     def forward(self, frames_energy, frames_pitch, mel_specs, output_lengths):
         lens = output_lengths if isinstance(output_lengths, Lengths) else Lengths(output_lengths)
         c = self.convs
-        packs = {'p0': c[0].conv.pack, 'p1': c[4].conv.pack, 'p2': c[8].conv.pack}
+        packs = {'p0': c[0].conv.pack, 'p1': c[4].conv.pack, 'p2': c[8].conv.pack,
+                 'params': {'c0_w': c[0].conv.weight, 'c0_b': c[0].conv.bias, 'l0_w': c[2].weight, 'l0_b': c[2].bias,
+                            'c1_w': c[4].conv.weight, 'c1_b': c[4].conv.bias, 'l1_w': c[6].weight, 'l1_b': c[6].bias,
+                            'c2_w': c[8].conv.weight, 'c2_b': c[8].conv.bias, 'l2_w': c[10].weight, 'l2_b': c[10].bias}}
         pe = positional_table(self.cfg['hidden_embed_dim'], mel_specs.device)
         x = Fx.AccentFrontFn.apply(mel_specs, frames_energy, frames_pitch, lens, packs, pe, self.cfg['conv_dropout'], self.training,
                                    c[0].conv.weight, c[0].conv.bias, c[2].weight, c[2].bias,

@@ -72,30 +72,79 @@ def _rows(t):
     return ld
 
 
+_PACK_TABLES = {}
+_ALL_PACKS = []      # weak registry of every PackedWeight (for the one-launch batched re-pack)
+
+
+def repack_all(packs=None) -> int:
+    """Re-packs every stale PackedWeight with ONE kernel launch (after an optimiser step); returns the number packed."""
+    import struct
+    import weakref  # noqa: F401
+    live = [r() for r in _ALL_PACKS] if packs is None else list(packs)
+    stale = []
+    for pk in live:
+        if pk is None or not pk.weight.is_cuda:
+            continue
+        if pk._current_key() != pk._key:
+            pk._ensure_buffers()
+            stale.append(pk)
+    if not stale:
+        return 0
+    bf16 = _PRECISION['bf16']
+    sig = tuple((pk.weight.data_ptr(), pk.fwd.data_ptr(), pk.bwd.data_ptr()) for pk in stale)
+    table = _PACK_TABLES.get(sig)
+    if table is None:                      # the descriptor table only changes when buffers are (re)allocated: upload it once
+        recs = b''.join(struct.pack('<QQQ8i', pk.weight.data_ptr(), pk.fwd.data_ptr(), pk.bwd.data_ptr(), pk.cout, pk.cin, pk.taps,
+                                     pk.dims[0], pk.dims[1], pk.dims[2], pk.dims[3], 0) for pk in stale)
+        table = torch.frombuffer(bytearray(recs), dtype=torch.uint8).to(stale[0].weight.device)
+        if len(_PACK_TABLES) > 8:
+            _PACK_TABLES.clear()
+        _PACK_TABLES[sig] = table
+    lib().dx_pack_weights_batched(_p(table), len(stale), bf16, _stream())
+    for pk in stale:
+        pk.bf16 = bf16
+        pk._key = pk._current_key()
+    return len(stale)
+
+
 class PackedWeight:
     """MFMA-ready copies of one (Cout, Cin[, taps]) parameter, refreshed when the parameter (or the precision) changes."""
 
     def __init__(self, weight: torch.Tensor):
+        import weakref
         self.weight = weight
         self.cout, self.cin = weight.shape[0], weight.shape[1]
         self.taps = weight.shape[2] if weight.dim() == 3 else 1
         self._key = None
         self.fwd = self.bwd = None
         self.bf16 = 0
+        self.dims = None
+        _ALL_PACKS.append(weakref.ref(self))
+        if len(_ALL_PACKS) > 4096:
+            _ALL_PACKS[:] = [r for r in _ALL_PACKS if r() is not None]
 
-    def refresh(self):
+    def _current_key(self):
         w = self.weight
-        key = (w._version, w.data_ptr(), _PRECISION['bf16'], _PACK_EPOCH[0])
-        if key == self._key:
-            return self
+        return (w._version, w.data_ptr(), _PRECISION['bf16'], _PACK_EPOCH[0])
+
+    def _ensure_buffers(self):
+        w = self.weight
         bf16 = _PRECISION['bf16']
-        dims = (ctypes.c_int * 4)()
-        lib().dx_pack_dims(self.cout, self.cin, bf16, ctypes.cast(dims, ctypes.c_void_p))
         dt = torch.bfloat16 if bf16 else torch.float32
         if self.fwd is None or self.fwd.dtype != dt or self.fwd.device != w.device:
-            self.fwd = torch.empty(self.taps * int(dims[0]) * int(dims[1]), dtype=dt, device=w.device)
-            self.bwd = torch.empty(self.taps * int(dims[2]) * int(dims[3]), dtype=dt, device=w.device)
-        lib().dx_pack_weights(_p(w.detach()), _p(self.fwd), _p(self.bwd), self.cout, self.cin, self.taps, bf16, _stream())
+            dims = (ctypes.c_int * 4)()
+            lib().dx_pack_dims(self.cout, self.cin, bf16, ctypes.cast(dims, ctypes.c_void_p))
+            self.dims = [int(d) for d in dims]
+            self.fwd = torch.empty(self.taps * self.dims[0] * self.dims[1], dtype=dt, device=w.device)
+            self.bwd = torch.empty(self.taps * self.dims[2] * self.dims[3], dtype=dt, device=w.device)
+
+    def refresh(self):
+        key = self._current_key()
+        if key == self._key:
+            return self
+        self._ensure_buffers()
+        bf16 = _PRECISION['bf16']
+        lib().dx_pack_weights(_p(self.weight.detach()), _p(self.fwd), _p(self.bwd), self.cout, self.cin, self.taps, bf16, _stream())
         self.bf16 = bf16
         self._key = key
         return self
@@ -154,21 +203,29 @@ def _zeros(arena, *shape, device=None):
     return arena.take(*shape) if arena is not None else torch.zeros(*shape, dtype=torch.float32, device=device)
 
 
-def conv_wgrad(dy, x, pack: PackedWeight, lens=None, halo=-1, bias=True, arena=None):
+def conv_wgrad(dy, x, pack: PackedWeight, lens=None, halo=-1, bias=True, arena=None, w_sink=None, b_sink=None):
     """(dW, db): gradient w.r.t. the (Cout, Cin[, taps]) parameter in its own layout, and the bias gradient (column sums of
-    dY, accumulated by the same launch)."""
+    dY, accumulated by the same launch).  ``w_sink`` / ``b_sink``: pre-zeroed ``.grad`` tensors to accumulate into directly
+    (the corresponding return value is then None)."""
     B_, N_ = (1, x.shape[0]) if x.dim() == 2 else (x.shape[0], x.shape[1])
-    g = _zeros(arena, pack.taps * pack.cout * pack.cin, device=x.device)
-    db = _zeros(arena, pack.cout, device=x.device) if bias else None
+    direct = w_sink is not None and pack.taps == 1          # Linear: G has the parameter's own layout
+    g = w_sink.view(-1) if direct else _zeros(arena, pack.taps * pack.cout * pack.cin, device=x.device)
+    db = b_sink if b_sink is not None else (_zeros(arena, pack.cout, device=x.device) if bias else None)
     if _LAUNCH_LOG[0] is not None:
         _LAUNCH_LOG[0].append(('wgrad', B_ * N_, N_, pack.cin, pack.cout, pack.taps))
     lib().dx_conv_wgrad(_p(dy), _rows(dy), _p(x), _rows(x), _p(g), B_, N_, pack.cin, pack.cout, pack.taps, _p(lens), int(halo),
                         _PRECISION['bf16'], _is_bf16(dy), _is_bf16(x), _p(db), _stream())
+    db_ret = None if b_sink is not None else db
+    if direct:
+        return None, db_ret
     if pack.taps == 1:
-        return g.view(pack.weight.shape), db
+        return g.view(pack.weight.shape), db_ret
+    if w_sink is not None:
+        lib().dx_unpack_wgrad(_p(g), _p(w_sink), pack.cout, pack.cin, pack.taps, 1, _stream())
+        return None, db_ret
     grad = torch.empty(pack.weight.shape, dtype=torch.float32, device=x.device)
     lib().dx_unpack_wgrad(_p(g), _p(grad), pack.cout, pack.cin, pack.taps, 0, _stream())
-    return grad, db
+    return grad, db_ret
 
 
 def colsum(x, C=None):
@@ -210,18 +267,18 @@ def ln_fwd(a, res, w, b, film, lens, *, seed_pre=0, p_pre=0.0, seed_post=0, p_po
 
 
 def ln_bwd(dy, z, mean, rstd, w, b, film, lens, *, relu_mask=False, want_da=False, seed_pre=0, p_pre=0.0, seed_post=0, p_post=0.0,
-           arena=None):
-    """Returns (dz, da or None, dw, db, dfilm or None)."""
+           arena=None, w_sink=None, b_sink=None):
+    """Returns (dz, da or None, dw, db, dfilm or None); dw/db are None when accumulated straight into the given sinks."""
     B, N, C = z.shape
     dz = torch.empty_like(z)
     da = torch.empty_like(z) if want_da else None
-    dw = _zeros(arena, C, device=z.device)
-    db = _zeros(arena, C, device=z.device)
+    dw = w_sink if w_sink is not None else _zeros(arena, C, device=z.device)
+    db = b_sink if b_sink is not None else _zeros(arena, C, device=z.device)
     dfilm = _zeros(arena, B, 2 * C, device=z.device) if film is not None else None
     lib().dx_ln_bwd(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(film), 0 if film is None else film.stride(0), _p(lens),
                     _p(dz), _p(da), _p(dw), _p(db), _p(dfilm), 2 * C, B, N, C, int(relu_mask),
                     seed_pre, float(p_pre), seed_post, float(p_post), _stream())
-    return dz, da, dw, db, dfilm
+    return dz, da, (None if w_sink is not None else dw), (None if b_sink is not None else db), dfilm
 
 
 def add_pos(x, sym, emb, pe, lens):
