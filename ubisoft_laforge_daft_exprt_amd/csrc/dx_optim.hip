@@ -1,0 +1,83 @@
+// Fused optimiser step over flat parameter / gradient buckets.
+// Replaces torch.optim.Adam(betas, eps, weight_decay as L2-in-gradient, amsgrad=False) + clip_grad_norm_ as the reference
+// trainer calls them (src/daft_exprt/train.py:278-280, :443-445): 14.4 M parameters x (read p, g, m, v; write p, m, v) =
+// 0.4 GB of pure HBM traffic per step, one launch per bucket instead of ~10 ATen launches per parameter tensor.
+#include "dx_common.h"
+#include <algorithm>
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+  __shared__ float part[4];
+  float s = 0.f;
+  const long n4 = n / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  if (blockIdx.x == 0)
+    for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) s += x[i] * x[i];
+  s = dx_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+struct AdamArgs {
+  float* p; const float* g; float* m; float* v; long n;
+  float lr, b1, b2, eps, wd, bc1, bc2_sqrt;
+  const float* normsq; float max_norm;
+};
+
+__device__ __forceinline__ float adam_one(float& p, float g, float& m, float& v, const AdamArgs& a, float coef) {
+  g = g * coef + a.wd * p;                             // clip, then L2 weight decay folded into the gradient (torch Adam)
+  m = a.b1 * m + (1.f - a.b1) * g;
+  v = a.b2 * v + (1.f - a.b2) * g * g;
+  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+  p -= (a.lr / a.bc1) * (m / denom);
+  return p;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
+  float coef = 1.f;
+  if (a.normsq && a.max_norm < INFINITY) coef = fminf(1.f, a.max_norm / (sqrtf(*a.normsq) + 1e-6f));  // clip_grad_norm_
+  const long n4 = a.n / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 p = reinterpret_cast<float4*>(a.p)[i], m = reinterpret_cast<float4*>(a.m)[i], v = reinterpret_cast<float4*>(a.v)[i];
+    const float4 g = reinterpret_cast<const float4*>(a.g)[i];
+    adam_one(p.x, g.x, m.x, v.x, a, coef); adam_one(p.y, g.y, m.y, v.y, a, coef);
+    adam_one(p.z, g.z, m.z, v.z, a, coef); adam_one(p.w, g.w, m.w, v.w, a, coef);
+    reinterpret_cast<float4*>(a.p)[i] = p; reinterpret_cast<float4*>(a.m)[i] = m; reinterpret_cast<float4*>(a.v)[i] = v;
+  }
+  if (blockIdx.x == 0)
+    for (long i = n4 * 4 + threadIdx.x; i < a.n; i += 256) adam_one(a.p[i], a.g[i], a.m[i], a.v[i], a, coef);
+}
+
+}  // namespace
+
+extern "C" {
+
+// out[0] += sum x^2   (global gradient norm; out is caller-zeroed)
+int dx_sumsq(const float* x, long n, float* out, void* stream) {
+  DX_REQUIRE(x && out && n > 0 && ((uintptr_t)x % 16) == 0, "dx_sumsq: bad arguments");
+  const int blocks = (int)std::min<long>((n / 4 + 255) / 256 + 1, 2048);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, out);
+  DX_LAUNCH_CHECK("dx_sumsq");
+  return DX_OK;
+}
+
+// One Adam step on a flat bucket.  step >= 1.  normsq (optional, device scalar) = squared global gradient norm for clipping.
+int dx_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int step, const float* normsq, float max_norm, void* stream) {
+  DX_REQUIRE(p && g && m && v && n > 0 && step >= 1, "dx_adam_step: bad arguments");
+  DX_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
+             "dx_adam_step: buffers must be 16-byte aligned");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  AdamArgs a{p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), normsq, max_norm};
+  const int blocks = (int)std::min<long>((n / 4 + 255) / 256 + 1, 4096);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  DX_LAUNCH_CHECK("dx_adam_step");
+  return DX_OK;
+}
+
+}  // extern "C"

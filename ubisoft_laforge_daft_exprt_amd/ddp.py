@@ -79,6 +79,9 @@ class GradientReducer:
 
     def finish(self):
         """Call after backward: waits for the collectives; gradients are then averaged over ranks."""
+        if any(n != 0 for n in self.pending):
+            raise RuntimeError(f'gradient bookkeeping out of balance after backward: pending per bucket = {self.pending} '
+                               '(a parameter received no gradient, or was counted twice)')
         for work, bi, op in self.works:
             work.wait()
             if op == dist.ReduceOp.SUM and self.world > 1:

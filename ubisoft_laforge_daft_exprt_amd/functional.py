@@ -31,8 +31,9 @@ def next_seed() -> int:
 # ----------------------------------------------------------------------------------------------------------------------
 # gradient sink: when a trainer pre-allocates (and zeroes) ``param.grad`` -- as ddp.GradientReducer does with views into its
 # communication buckets -- the backward kernels accumulate straight into it (atomics / accumulate epilogues) and hand
-# autograd ``None``: no temporary gradient tensor, no ATen ``+=`` launch per parameter.  ``_GRAD_SINK['hook']`` is called
-# with the parameter once its gradient is complete (the reducer's bucket bookkeeping).
+# autograd ``None``: no temporary gradient tensor, no ATen ``+=`` launch per parameter.  The autograd engine still runs the
+# parameter's post-accumulate hooks for an undefined gradient (torch 2.10), which is what drives the reducer's bucket
+# bookkeeping; GradientReducer.finish() raises if that ever stops being true.
 # ----------------------------------------------------------------------------------------------------------------------
 _GRAD_SINK = {'enabled': False, 'hook': None}
 
@@ -49,13 +50,6 @@ def _sink(param):
     if g is None or not g.is_contiguous() or g.dtype != torch.float32:
         return None
     return g
-
-
-def _sunk(*params):
-    hook = _GRAD_SINK['hook']
-    if hook is not None:
-        for p in params:
-            hook(p)
 
 
 class Lengths:
@@ -193,7 +187,6 @@ class FFTBlockFn(torch.autograd.Function):
         dqkv = ops.attention_bwd(qkv, att, datt, lse, L, ctx.heads, s_attn, p_attn)
         din_w, din_b = ops.conv_wgrad(dqkv, x, packs['in'], L, 0, arena=arena, w_sink=g('in_w'), b_sink=g('in_b'))
         dx = ops.conv_gemm(dqkv, packs['in'], None, transpose=True, out=dz1, accumulate=True, lens=L, halo=0)  # + residual branch
-        _sunk(*[P[k] for k, v in sk.items() if v is not None])
         return (dx, dfilm, None, None, None, None,
                 din_w, din_b, dout_w, dout_b, dln1_w, dln1_b, dc1_w, dc1_b, dc2_w, dc2_b, dln2_w, dln2_b)
 
@@ -242,7 +235,6 @@ class AccentFrontFn(torch.autograd.Function):
         dz0, _, dl0_w, dl0_b, _ = ops.ln_bwd(dy0, h0, m0, r0, l0_w, l0_b, None, None, relu_mask=True, seed_post=seeds[0], p_post=p,
                                               w_sink=g('l0_w'), b_sink=g('l0_b'))
         dc0_w, dc0_b = ops.conv_wgrad(dz0, x0, packs['p0'], L, 2, w_sink=g('c0_w'), b_sink=g('c0_b'))
-        _sunk(*[P[k] for k, v in sk.items() if v is not None])
         return (None, None, None, None, None, None, None, None,
                 dc0_w, dc0_b, dl0_w, dl0_b, dc1_w, dc1_b, dl1_w, dl1_b, dc2_w, dc2_b, dl2_w, dl2_b, dwe, dbe, dwp, dbp)
 
