@@ -253,3 +253,73 @@ def test_fused_adam_matches_torch_adam(dx):
             assert ((a - b).abs().max() <= 2e-6 * a.abs().max()).item()
     hp = helpers.golden_hparams(initial_learning_rate=1e-4, max_learning_rate=1e-3, warmup_steps=10000)
     assert abs(update_learning_rate(hp, 5000) - 5.5e-4) < 1e-12 and abs(update_learning_rate(hp, 40000) - 5e-4) < 1e-12
+
+
+def _c5_batch(n_speakers):
+    """Long-form stress batch (BASELINE.json config 5 shape: L up to 500, decoder T ~ 4000); utterance 0 is the longest on
+    BOTH axes so that it sees no padding in the batch (then its result must not depend on the other utterances)."""
+    from ubisoft_laforge_daft_exprt_amd.synth import synthetic_batch
+    g = torch.Generator().manual_seed(55)
+    lens = [500, 470, 455, 430, 410, 401]
+    dur = torch.randint(4, 12, (len(lens), 500), generator=g)
+    dur[0] = 9                                               # 4500 frames: the longest row, below the 5000-row position table
+    return synthetic_batch(len(lens), (400, 500), seed=56, n_speakers=n_speakers, sym_lengths=lens, durations_int=dur)
+
+
+def test_long_form_c5_properties_and_single_utterance_oracle(dx):
+    from oracle import daft_exprt_oracle as oracle
+    hp = helpers.golden_hparams()
+    batch = _c5_batch(hp.n_speakers)
+    model = build_model(dx, hp)
+    model.train()
+    crit = build_loss(dx, hp)
+    inputs, targets = model.parse_batch(DEV, batch)
+    out = model(inputs)
+    total, _ = crit(out, targets + (inputs[6], inputs[7]), 3000)
+    total.backward()
+    mel, weights = out[3][0].detach(), out[4].detach()
+    out_lens, in_lens = batch[9], batch[5]
+    assert mel.shape == (6, 80, 4500) and weights.shape == (6, 500, 4500)          # T_max = max cumsum: exact
+    assert torch.isfinite(total) and all(torch.isfinite(p.grad).all() for p in model.parameters())
+    for b in range(6):
+        assert (mel[b, :, int(out_lens[b]):] == 0).all()
+        assert (weights[b, int(in_lens[b]):] == 0).all()                               # padded symbols get no weight
+        colsum = weights[b, :, :int(out_lens[b])].sum(0)
+        # p / (sum p + 1e-20): a frame's weights sum to 1, or to less where every Gaussian underflows (narrow ranges) -- never more
+        assert colsum.max() < 1 + 1e-4 and colsum.min() >= 0 and (colsum > 0.999).float().mean() > 0.5
+    # batch independence for the unpadded utterance: run it alone
+    single = tuple(t[:1] if torch.is_tensor(t) else t[:1] for t in batch)
+    with torch.no_grad():
+        model.eval()
+        out1 = model(model.parse_batch(DEV, single)[0])
+        outb = model(inputs)
+    assert (out1[3][0][0] - outb[3][0][0]).abs().max() < 2e-5
+    assert (out1[4][0] - outb[4][0]).abs().max() < 1e-5
+    # and against the CPU oracle (B = 1: the 500 x 128 x 4500 broadcast still fits)
+    sd = helpers.golden_state_dict()
+    cpu_inputs = tuple(single[i] for i in range(11)) + (single[13],)
+    with torch.no_grad():
+        ref = oracle.forward(sd, cpu_inputs, hp)
+    l1 = valid_mel_l1(out1[3][0].cpu().numpy(), ref[3][0].numpy(), single[9])
+    print('long-form (L=500, T=4500) valid mel L1 vs oracle', l1)
+    assert l1 < 2e-5
+    assert np.abs(out1[4].cpu().numpy() - ref[4].numpy()).max() < 2e-4
+
+
+def test_long_form_bf16_mode_runs_and_tracks_fp32(dx):
+    """bf16 operand mode on the long-form shape: finite, masked, and close to the fp32 path (stated tolerance: 5e-2 mel L1)."""
+    hp = helpers.golden_hparams()
+    batch = _c5_batch(hp.n_speakers)
+    model = build_model(dx, hp).eval()
+    inputs, _ = model.parse_batch(DEV, batch)
+    with torch.no_grad():
+        ref = model(inputs)[3][0]
+        dx.set_precision('bf16')
+        try:
+            got = model(inputs)[3][0]
+        finally:
+            dx.set_precision('f32')
+    assert torch.isfinite(got).all()
+    l1 = valid_mel_l1(got.cpu().numpy(), ref.cpu().numpy(), batch[9])
+    print('bf16-vs-f32 valid mel L1 (long form)', l1)
+    assert l1 < 5e-2
