@@ -323,3 +323,36 @@ def test_long_form_bf16_mode_runs_and_tracks_fp32(dx):
     l1 = valid_mel_l1(got.cpu().numpy(), ref.cpu().numpy(), batch[9])
     print('bf16-vs-f32 valid mel L1 (long form)', l1)
     assert l1 < 5e-2
+
+
+def test_graph_captured_inference_matches_eager_and_golden(dx):
+    """f-3: host pre-processing first, then ONE captured HIP graph for the device forward; replay == eager == reference."""
+    import time
+    from ubisoft_laforge_daft_exprt_amd.inference import GraphedSynthesizer
+    case = helpers.load_case('inference_add')
+    hp = helpers.golden_hparams(stats={'spk 0': {'pitch': {'mean': 5.0, 'std': 0.25}}, 'spk 1': {'pitch': {'mean': 4.6, 'std': 0.3}}})
+    model = build_model(dx, hp).eval()
+    synth = GraphedSynthesizer(model, hp)
+    t = lambda k: torch.from_numpy(case[k]).clone().to(DEV)
+
+    def args():
+        inputs = (t('in/symbols'), t('in/dur_factors'), t('in/energy_factors'), t('in/pitch_factors'), t('in/input_lengths'), t('in/speaker_ids'))
+        prosody = {k: t('in/prosody_' + k) for k in ('duration_preds', 'durations_int', 'energy_preds', 'pitch_preds')}
+        return inputs, 'add', prosody, t('in/spk_embs'), t('in/accent_emb')
+
+    enc_e, (mel_e, len_e), w_e = synth(*args(), use_graph=False)
+    enc_g, (mel_g, len_g), w_g = synth(*args(), use_graph=True)           # captures
+    enc_r, (mel_r, len_r), w_r = synth(*args(), use_graph=True)           # replays
+    assert len(synth.graphs) == 1
+    assert torch.equal(mel_e, mel_g) and torch.equal(mel_g, mel_r) and torch.equal(w_e, w_r)
+    assert np.array_equal(enc_r[1].cpu().numpy(), case['out/durations_int']) and np.array_equal(len_r.cpu().numpy(), case['out/output_lengths'])
+    assert valid_mel_l1(mel_r.cpu().numpy(), case['out/mel'], len_r.cpu()) < 2e-5
+    # replay with different data of the same padded shape (other speaker embeddings) must track the eager path
+    a = list(args())
+    a[3] = a[3] * 0.5 + 0.1
+    _, (mel_e2, _), _ = synth(*a, use_graph=False)
+    a = list(args())
+    a[3] = a[3] * 0.5 + 0.1
+    _, (mel_g2, _), _ = synth(*a, use_graph=True)
+    assert torch.equal(mel_e2, mel_g2) and not torch.equal(mel_g2, mel_r)
+    assert len(synth.graphs) == 1
