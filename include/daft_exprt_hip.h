@@ -119,6 +119,11 @@ int dx_mel_grad(const float* mel_pred, const float* mel_target, const float* ep,
 int dx_pitch_mse(const float* pp, const float* gt, const int* lens, float* sums, int B, int T, void* stream);
 int dx_pitch_grad(const float* pp, const float* gt, const int* lens, const float* sums, float scale, float* dpp, int B, int T, void* stream);
 
+/* ---- on-device batch conditioning: dynamic_stats.py:131-195 ------------------------------------------------ */
+int dx_condition_prosody(const float* in, float* out, const long* speaker_ids, const float* table, const int* valid,
+                         int which, int B, int N, int S, void* stream);
+int dx_gather_speaker_rows(const float* emb, const long* speaker_ids, const int* valid, float* out, int B, int E, int S, void* stream);
+
 /* ---- fused optimiser step: train.py:278-280 (Adam), :443 (clip_grad_norm_) ------------------------------ */
 int dx_sumsq(const float* x, long n, float* out, void* stream);
 int dx_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,

@@ -463,3 +463,27 @@ def inference(sd, inputs, pitch_transform, hp, external_prosody=None, external_e
     assert int(out_lens.max()) == x_up.shape[1]
     mel = frame_decoder(sd, x_up, film['frame_decoder'], out_lens, hp)
     return [dur, dur_int, energy, pitch, in_lens], [mel, out_lens], weights
+
+
+# ----------------------------------------------------------------------------------------------
+# batch conditioning
+# ----------------------------------------------------------------------------------------------
+def process_batch(inputs, current_stats):
+    """DynamicSpeakerStatsManager.process_batch, dynamic_stats.py:131-195 (host loop over the speakers of the batch)."""
+    (symbols, dur_f, dur_i, sym_e, sym_p, in_l, frm_e, frm_p, mel, out_l, speaker_ids, spk_embs) = inputs
+    frm_e, frm_p, sym_e, sym_p = frm_e.clone(), frm_p.clone(), sym_e.clone(), sym_p.clone()
+    dim = next(iter(current_stats.values()))['spk_emb'].shape[0]
+    avg = torch.zeros(len(speaker_ids), dim)
+    for spk in torch.unique(speaker_ids):
+        sid = spk.item()
+        if sid not in current_stats:
+            continue
+        st, rows = current_stats[sid], speaker_ids == spk
+        for t, kind in ((frm_e, 'energy'), (sym_e, 'energy'), (frm_p, 'pitch'), (sym_p, 'pitch')):
+            v = t[rows]
+            zero = v == 0.0
+            v = (v - st[kind]['mean']) / st[kind]['std']
+            v[zero] = 0.0
+            t[rows] = v
+        avg[rows] = st['spk_emb']
+    return (symbols, dur_f, dur_i, sym_e, sym_p, in_l, frm_e, frm_p, mel, out_l, speaker_ids, avg)

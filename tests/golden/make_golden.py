@@ -246,6 +246,31 @@ def capture_duration_kats(hp):
     print('duration KATs:', [k['expected'] for k in kats[:5]])
 
 
+def capture_batch_conditioning():
+    """DynamicSpeakerStatsManager.process_batch (dynamic_stats.py:131-195) with hand-set support-set statistics; the constructor
+    (file lists, refresh_stats I/O) is bypassed -- only the per-batch conditioning is on the path."""
+    from daft_exprt.dynamic_stats import DynamicSpeakerStatsManager
+    batch = synthetic_batch(9, (10, 30), seed=3, n_speakers=6)
+    inputs = tuple(batch[i] for i in range(11)) + (batch[13],)
+    inputs = inputs[:10] + (torch.tensor([0, 1, 2, 2, 4, 0, 1, 7, 4]),) + inputs[11:]
+    g = torch.Generator().manual_seed(1)
+    stats = {s: {'pitch': {'mean': 4.5 + 0.1 * s, 'std': 0.2 + 0.05 * s}, 'energy': {'mean': 1.0 + s, 'std': 0.5 + 0.1 * s},
+                 'spk_emb': torch.randn(192, generator=g)} for s in (0, 1, 4)}
+    mgr = object.__new__(DynamicSpeakerStatsManager)
+    mgr.current_stats = stats
+    out = mgr.process_batch(inputs, 'cpu')
+    rec = {}
+    for n, t in zip(INPUT_NAMES, inputs):
+        rec['in/' + n] = np_(t)
+    for n, t in zip(INPUT_NAMES, out):
+        rec['out/' + n] = np_(t)
+    for s, st in stats.items():
+        rec[f'stats/{s}'] = np.array([st['energy']['mean'], st['energy']['std'], st['pitch']['mean'], st['pitch']['std']])
+        rec[f'emb/{s}'] = np_(st['spk_emb'])
+    np.savez_compressed(os.path.join(HERE, 'batch_conditioning.npz'), **rec)
+    print('batch_conditioning: speakers with stats', sorted(stats))
+
+
 def main():
     hp = HyperParams(n_speakers=3).without_dropout()
     assert len(symbols_english) == hp.n_symbols
@@ -267,6 +292,7 @@ def main():
     capture_inference_case('inference_add', hp, 'add')
     capture_inference_case('inference_multiply', hp, 'multiply')
     capture_duration_kats(hp)
+    capture_batch_conditioning()
 
 
 if __name__ == '__main__':

@@ -356,3 +356,24 @@ def test_graph_captured_inference_matches_eager_and_golden(dx):
     _, (mel_g2, _), _ = synth(*a, use_graph=True)
     assert torch.equal(mel_e2, mel_g2) and not torch.equal(mel_g2, mel_r)
     assert len(synth.graphs) == 1
+
+
+def test_batch_conditioning_matches_reference_semantics(dx):
+    """f-2: per-speaker zero-preserving z-normalisation + support-set embedding, on the device, vs the host-loop restatement."""
+    from oracle import daft_exprt_oracle as oracle
+    from ubisoft_laforge_daft_exprt_amd.conditioning import BatchConditioner
+    from ubisoft_laforge_daft_exprt_amd.synth import synthetic_batch
+    batch = synthetic_batch(9, (10, 30), seed=3, n_speakers=6)
+    inputs = tuple(batch[i] for i in range(11)) + (batch[13],)
+    inputs = inputs[:10] + (torch.tensor([0, 1, 2, 2, 4, 0, 1, 7, 4]),) + inputs[11:]      # speakers 2? unknown: 2 and 7 have no stats
+    g = torch.Generator().manual_seed(1)
+    stats = {s: {'pitch': {'mean': 4.5 + 0.1 * s, 'std': 0.2 + 0.05 * s}, 'energy': {'mean': 1.0 + s, 'std': 0.5 + 0.1 * s},
+                 'spk_emb': torch.randn(192, generator=g)} for s in (0, 1, 4)}
+    ref = oracle.process_batch(inputs, stats)
+    cond = BatchConditioner(stats, DEV)
+    got = cond.process_batch(tuple(t.to(DEV) for t in inputs))
+    for i in (3, 4, 6, 7, 11):
+        assert torch.allclose(got[i].cpu(), ref[i], rtol=1e-6, atol=1e-7), i
+        assert torch.equal(got[i].cpu() == 0, ref[i] == 0)                                # exact zeros preserved
+    for i in (0, 1, 2, 5, 8, 9, 10):
+        assert torch.equal(got[i].cpu(), ref[i])

@@ -120,3 +120,19 @@ def test_error_behaviour():
         oracle.forward(sd, inputs[:11], hp)
     with pytest.raises(ValueError):
         oracle.forward(sd, inputs[:11] + (None,), hp)
+
+
+def test_batch_conditioning_vs_reference():
+    """oracle.process_batch against DynamicSpeakerStatsManager.process_batch outputs (f-2)."""
+    case = helpers.load_case('batch_conditioning')
+    inputs = tuple(torch.from_numpy(case['in/' + n]) for n in helpers.INPUT_NAMES)
+    stats = {}
+    for k in case:
+        if k.startswith('stats/'):
+            s = int(k.split('/')[1])
+            v = case[k]
+            stats[s] = {'energy': {'mean': float(v[0]), 'std': float(v[1])}, 'pitch': {'mean': float(v[2]), 'std': float(v[3])},
+                        'spk_emb': torch.from_numpy(case[f'emb/{s}'])}
+    out = oracle.process_batch(inputs, stats)
+    for n, t in zip(helpers.INPUT_NAMES, out):
+        assert np.array_equal(t.numpy(), case['out/' + n]), n

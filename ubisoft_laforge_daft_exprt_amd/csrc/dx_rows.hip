@@ -457,6 +457,30 @@ __global__ __launch_bounds__(256) void channel_affine_kernel(const float* __rest
   }
 }
 
+// per-speaker z-normalisation that preserves exact zeros (silence / unvoiced): dynamic_stats.py:156-183
+// table[s] = {energy mean, energy std, pitch mean, pitch std}; valid[s] = 0 -> utterance left untouched
+__global__ __launch_bounds__(256) void condition_prosody_kernel(const float* __restrict__ in, float* __restrict__ out, const long* __restrict__ spk,
+                                                                const float* __restrict__ table, const int* __restrict__ valid,
+                                                                int which, int N, int S) {
+  const int b = blockIdx.y;
+  const long s = spk[b];
+  const bool ok = s >= 0 && s < S && valid[s];
+  const float mean = ok ? table[s * 4 + which * 2] : 0.f, sd = ok ? table[s * 4 + which * 2 + 1] : 1.f;
+  for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += gridDim.x * 256) {
+    const float v = in[(size_t)b * N + n];
+    out[(size_t)b * N + n] = ok ? (v == 0.f ? 0.f : (v - mean) / sd) : v;
+  }
+}
+
+// out[b,:] = valid[spk[b]] ? emb[spk[b],:] : 0     (support-set mean speaker embedding, dynamic_stats.py:185-186)
+__global__ __launch_bounds__(256) void gather_speaker_rows_kernel(const float* __restrict__ emb, const long* __restrict__ spk, const int* __restrict__ valid,
+                                                                  float* __restrict__ out, int E, int S) {
+  const int b = blockIdx.x;
+  const long s = spk[b];
+  const bool ok = s >= 0 && s < S && valid[s];
+  for (int e = threadIdx.x; e < E; e += 256) out[(size_t)b * E + e] = ok ? emb[(size_t)s * E + e] : 0.f;
+}
+
 inline int row_grid(long rows) { return (int)std::min<long>((rows + 3) / 4, 8192); }
 
 }  // namespace
@@ -604,6 +628,22 @@ int dx_channel_affine(const float* x, const float* scale, const float* shift, fl
   const long total4 = rows * C / 4;
   hipLaunchKernelGGL(channel_affine_kernel, dim3((int)std::min<long>((total4 + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, out, rows, C);
   DX_LAUNCH_CHECK("dx_channel_affine");
+  return DX_OK;
+}
+
+int dx_condition_prosody(const float* in, float* out, const long* speaker_ids, const float* table, const int* valid,
+                         int which, int B, int N, int S, void* stream) {
+  DX_REQUIRE(in && out && speaker_ids && table && valid && (which == 0 || which == 1) && B > 0 && N > 0 && S > 0, "dx_condition_prosody: bad arguments");
+  hipLaunchKernelGGL(condition_prosody_kernel, dim3(std::max(1, std::min(dx_cdiv(N, 256), 16)), B), dim3(256), 0, (hipStream_t)stream,
+                     in, out, speaker_ids, table, valid, which, N, S);
+  DX_LAUNCH_CHECK("dx_condition_prosody");
+  return DX_OK;
+}
+
+int dx_gather_speaker_rows(const float* emb, const long* speaker_ids, const int* valid, float* out, int B, int E, int S, void* stream) {
+  DX_REQUIRE(emb && speaker_ids && valid && out && B > 0 && E > 0 && S > 0, "dx_gather_speaker_rows: bad arguments");
+  hipLaunchKernelGGL(gather_speaker_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, emb, speaker_ids, valid, out, E, S);
+  DX_LAUNCH_CHECK("dx_gather_speaker_rows");
   return DX_OK;
 }
 
