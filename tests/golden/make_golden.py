@@ -271,6 +271,26 @@ def capture_batch_conditioning():
     print('batch_conditioning: speakers with stats', sorted(stats))
 
 
+def capture_feature_collate(hp):
+    """DaftExprtDataLoader.get_data + DaftExprtDataCollate on deterministic synthetic feature files (f-4)."""
+    from daft_exprt.data_loader import DaftExprtDataLoader, DaftExprtDataCollate
+    from tests.helpers import write_synthetic_features, FEATURE_STATS
+    hp_f = hp.clone(stats=FEATURE_STATS, symbols=list(symbols_english), seed=1234)
+    with tempfile.TemporaryDirectory() as tmp:
+        list_file, _rows = write_synthetic_features(tmp)
+        rec = {}
+        for raw in (False, True):
+            ds = DaftExprtDataLoader(list_file, hp_f, shuffle=False, return_raw_stats=raw)
+            out = DaftExprtDataCollate(hp_f)([ds[i] for i in range(len(ds))])
+            tag = 'raw' if raw else 'norm'
+            for k, t in enumerate(out):
+                if torch.is_tensor(t):
+                    rec[f'{tag}/{k}'] = np_(t)
+            rec[f'{tag}/files'] = np.array(out[12])
+    np.savez_compressed(os.path.join(HERE, 'feature_collate.npz'), **rec)
+    print('feature_collate: files order', out[12])
+
+
 def main():
     hp = HyperParams(n_speakers=3).without_dropout()
     assert len(symbols_english) == hp.n_symbols
@@ -293,6 +313,7 @@ def main():
     capture_inference_case('inference_multiply', hp, 'multiply')
     capture_duration_kats(hp)
     capture_batch_conditioning()
+    capture_feature_collate(hp)
 
 
 if __name__ == '__main__':

@@ -49,3 +49,38 @@ def sample_like_golden(grad):
     g = grad.detach().flatten().double().cpu()
     stride = max(1, g.numel() // 256)
     return g.sum().item(), g.abs().sum().item(), g[::stride][:256].float().numpy()
+
+
+def write_synthetic_features(root, seed=21, n=5):
+    """Deterministic feature files in the reference's on-disk format (f-4); returns the list-file path and the rows."""
+    from ubisoft_laforge_daft_exprt_amd.features import SYMBOLS_ENGLISH
+    g = np.random.RandomState(seed)
+    os.makedirs(root, exist_ok=True)
+    rows = []
+    for i in range(n):
+        name, sid = f'utt{i:03d}', int(g.randint(0, 2))
+        L = int(g.randint(4, 12))
+        dur = g.randint(1, 7, size=L)
+        T = int(dur.sum())
+        t = 0.0
+        with open(os.path.join(root, name + '.markers'), 'w', encoding='utf-8') as f:
+            for l in range(L):
+                end = t + dur[l] * 256 / 22050 + 1e-3 * g.rand()
+                f.write(f'{t:.6f}\t{end:.6f}\t{int(dur[l])}\t{SYMBOLS_ENGLISH[int(g.randint(2, 76))]}\t{t:.3f}\t{end:.3f}\n')
+                t = end
+        np.save(os.path.join(root, name + '.npy'), (-5 + 2 * g.randn(80, T)).astype(np.float32))
+        for ext, count, zero_frac in (('symbols_nrg', L, 0.2), ('symbols_f0', L, 0.3), ('frames_nrg', T, 0.0), ('frames_f0', T, 0.3)):
+            vals = np.abs(g.randn(count)) * 3 + 0.1
+            vals[g.rand(count) < zero_frac] = 0.0
+            with open(os.path.join(root, f'{name}.{ext}'), 'w', encoding='utf-8') as f:
+                f.writelines(f'{v:.6f}\n' for v in vals)
+        np.save(os.path.join(root, name + '.spk_emb.npy'), g.randn(192).astype(np.float32))
+        rows.append((root, name, sid))
+    list_file = os.path.join(root, 'train.txt')
+    with open(list_file, 'w', encoding='utf-8') as f:
+        f.writelines(f'{d}|{n_}|{s}\n' for d, n_, s in rows)
+    return list_file, rows
+
+
+FEATURE_STATS = {'spk 0': {'energy': {'mean': 2.0, 'std': 1.5}, 'pitch': {'mean': 2.5, 'std': 1.2}},
+                 'spk 1': {'energy': {'mean': 1.7, 'std': 1.1}, 'pitch': {'mean': 2.2, 'std': 0.9}}}
