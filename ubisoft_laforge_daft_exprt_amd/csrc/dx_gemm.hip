@@ -24,6 +24,7 @@
 // zero, which is exactly the reference's zero 'same' padding on the padded (B, N_max) grid.
 #include "dx_common.h"
 #include <algorithm>
+#include <stdlib.h>
 
 namespace {
 
@@ -631,8 +632,11 @@ void launch_conv_inst(const ConvGemmArgs& a, hipStream_t s) {
 
 template <typename T, int TAPS>
 int launch_conv(const ConvGemmArgs& a, hipStream_t s) {
-  // narrow outputs (Cout <= 128: conv2, out-proj, mel projection ...) would launch fewer workgroups than there are CUs
-  const bool small = (long)a.B * dx_cdiv(a.N, TILE) * (a.CoutP / TILE) < 1024;
+  // narrow outputs (Cout <= 128: conv2, out-proj, mel projection ...) launch few workgroups: in exact-f32 mode (MFMA-paced)
+  // 64-token tiles fill the chip better (measured 405 -> 354 us on the FF conv2); in bf16 mode the 128-token tile stays ahead
+  // (62 vs 79 us) because the weight tile is re-staged half as often.
+  static const long small_below = getenv("DX_CONV_SMALL_BELOW") ? atol(getenv("DX_CONV_SMALL_BELOW")) : (sizeof(T) == 4 ? 1024 : 0);
+  const bool small = (long)a.B * dx_cdiv(a.N, TILE) * (a.CoutP / TILE) < small_below;
   if constexpr (sizeof(T) == 2) {
     if (a.x_bf16) { if (small) launch_conv_inst<T, TAPS, 64, true>(a, s); else launch_conv_inst<T, TAPS, 128, true>(a, s); return DX_OK; }
   }
@@ -731,7 +735,8 @@ int dx_conv_wgrad(const void* dY, int ldy, const void* X, int ldx, float* G,
     DX_REQUIRE(skip_halo < 0 || lens, "dx_conv_wgrad: skip_halo needs lens");
     const int tiles = dx_cdiv(Cout, TILE) * dx_cdiv(Cin, 64);
     const int total_chunks = B * dx_cdiv(N, WB_BK);
-    const int ksplit = std::max(1, std::min(total_chunks, dx_cdiv(768, tiles)));
+    static const int target_blocks = getenv("DX_WGRAD_BLOCKS") ? atoi(getenv("DX_WGRAD_BLOCKS")) : 384;   // split-K partials are fp32 atomics (~1.3 TB/s chip-wide): 384 blocks measured best (256..1024 swept)
+    const int ksplit = std::max(1, std::min(total_chunks, dx_cdiv(target_blocks, tiles)));
     WgradBf16Args a{dY, ldy, dy_bf16, X, ldx, x_bf16, G, B, N, Cin, Cout, ksplit, lens, skip_halo, dbias};
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(tiles, 1, ksplit);
