@@ -389,6 +389,25 @@ __device__ __forceinline__ void stage_tile_bf16(unsigned char* dst, const float*
   }
 }
 
+// software pipeline: the NEXT tile's rows are fetched into registers (4 x 16 bytes per thread per tensor) before the current
+// tile's MFMA/softmax work, and converted + written to LDS after it
+#define DX_TILE_LOAD(REG, BASE, LD, COL0, R0, NROWS)                                                              \
+  _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                                             \
+    const int u_ = tid + it * 256;                                                                                \
+    const int row_ = u_ >> 4, q_ = u_ & 15;                                                                       \
+    f32x4 v_ = f32x4{0.f, 0.f, 0.f, 0.f};                                                                         \
+    if ((R0) + row_ < (NROWS)) v_ = *reinterpret_cast<const f32x4*>((BASE) + (size_t)((R0) + row_) * (LD) + (COL0) + q_ * 4); \
+    REG[it] = v_;                                                                                                 \
+  }
+#define DX_TILE_STORE(REG, DST)                                                                                   \
+  _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                                             \
+    const int u_ = tid + it * 256;                                                                                \
+    const int row_ = u_ >> 4, q_ = u_ & 15;                                                                       \
+    bf16x4 h_;                                                                                                    \
+    h_[0] = (__bf16)REG[it][0]; h_[1] = (__bf16)REG[it][1]; h_[2] = (__bf16)REG[it][2]; h_[3] = (__bf16)REG[it][3]; \
+    *reinterpret_cast<uint2*>((DST) + sw_off(row_, q_ >> 1) + ((q_ & 1) << 3)) = __builtin_bit_cast(uint2, h_);  \
+  }
+
 // row fragment: 8 consecutive columns (32*ks + 8*g ..) of row `row`
 __device__ __forceinline__ bf16x8 row_frag(const unsigned char* tile, int row, int ks, int g) {
   return __builtin_bit_cast(bf16x8, *reinterpret_cast<const float4*>(tile + sw_off(row, ks * 4 + g)));
@@ -450,12 +469,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a)
   float m_run = -INFINITY, l_run = 0.f;
   const int bh = b * a.H + h;
   const int ntiles = (len + 63) / 64;
+  f32x4 kreg[4], vreg[4];
+  DX_TILE_LOAD(kreg, base, a.ld, a.D + h * HD, 0, a.N)
+  DX_TILE_LOAD(vreg, base, a.ld, 2 * a.D + h * HD, 0, a.N)
   for (int kt0 = 0; kt0 < ntiles; ++kt0) {
     const int kbase = kt0 * 64;
     __syncthreads();
-    stage_tile_bf16(Ks, base, a.ld, a.D + h * HD, kbase, a.N, tid, 1.f);
-    stage_tile_bf16(Vs, base, a.ld, 2 * a.D + h * HD, kbase, a.N, tid, 1.f);
+    DX_TILE_STORE(kreg, Ks)
+    DX_TILE_STORE(vreg, Vs)
     __syncthreads();
+    if (kt0 + 1 < ntiles) {
+      DX_TILE_LOAD(kreg, base, a.ld, a.D + h * HD, kbase + 64, a.N)
+      DX_TILE_LOAD(vreg, base, a.ld, 2 * a.D + h * HD, kbase + 64, a.N)
+    }
     f32x4 st[4];
     float mx = -INFINITY;
 #pragma unroll
@@ -542,12 +568,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ntiles = (len + 63) / 64;
+  f32x4 kreg[4], vreg[4];
+  DX_TILE_LOAD(kreg, base, a.ld, a.D + h * HD, 0, a.N)
+  DX_TILE_LOAD(vreg, base, a.ld, 2 * a.D + h * HD, 0, a.N)
   for (int kt0 = 0; kt0 < ntiles; ++kt0) {
     const int kbase = kt0 * 64;
     __syncthreads();
-    stage_tile_bf16(Ks, base, a.ld, a.D + h * HD, kbase, a.N, tid, 1.f);
-    stage_tile_bf16(Vs, base, a.ld, 2 * a.D + h * HD, kbase, a.N, tid, 1.f);
+    DX_TILE_STORE(kreg, Ks)
+    DX_TILE_STORE(vreg, Vs)
     __syncthreads();
+    if (kt0 + 1 < ntiles) {
+      DX_TILE_LOAD(kreg, base, a.ld, a.D + h * HD, kbase + 64, a.N)
+      DX_TILE_LOAD(vreg, base, a.ld, 2 * a.D + h * HD, kbase + 64, a.N)
+    }
     f32x4 ds[4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -620,17 +653,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwd
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   const int ntiles = (len + 63) / 64;
+  f32x4 qreg[4], greg[4];
+  float lse_r = 0.f, delta_r = 0.f;
+  DX_TILE_LOAD(qreg, base, a.ld, h * HD, 0, a.N)
+  DX_TILE_LOAD(greg, gbase, a.ldc, h * HD, 0, a.N)
+  if (tid < 64 && tid < a.N) { lse_r = a.lse[(size_t)bh * a.N + tid]; delta_r = a.delta[(size_t)bh * a.N + tid]; }
   for (int qt0 = 0; qt0 < ntiles; ++qt0) {
     const int qbase = qt0 * 64;
     __syncthreads();
-    stage_tile_bf16(Qs, base, a.ld, h * HD, qbase, a.N, tid, 1.f);
-    stage_tile_bf16(Gs, gbase, a.ldc, h * HD, qbase, a.N, tid, 1.f);
-    if (tid < 64) {
-      const int q = qbase + tid;
-      lse_s[tid] = q < a.N ? a.lse[(size_t)bh * a.N + q] : 0.f;
-      delta_s[tid] = q < a.N ? a.delta[(size_t)bh * a.N + q] : 0.f;
-    }
+    DX_TILE_STORE(qreg, Qs)
+    DX_TILE_STORE(greg, Gs)
+    if (tid < 64) { lse_s[tid] = lse_r; delta_s[tid] = delta_r; }
     __syncthreads();
+    if (qt0 + 1 < ntiles) {
+      DX_TILE_LOAD(qreg, base, a.ld, h * HD, qbase + 64, a.N)
+      DX_TILE_LOAD(greg, gbase, a.ldc, h * HD, qbase + 64, a.N)
+      const int qn = qbase + 64 + tid;
+      lse_r = (tid < 64 && qn < a.N) ? a.lse[(size_t)bh * a.N + qn] : 0.f;
+      delta_r = (tid < 64 && qn < a.N) ? a.delta[(size_t)bh * a.N + qn] : 0.f;
+    }
     f32x4 pd[4], ds[4];
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
@@ -672,6 +713,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwd
   }
 }
 #undef DX_MFMA_BF16
+#undef DX_TILE_LOAD
+#undef DX_TILE_STORE
 
 int check_common(const char* who, const void* qkv, int ld, int B, int N, int H, int D) {
   DX_REQUIRE(qkv != nullptr, "%s: null pointer", who);
