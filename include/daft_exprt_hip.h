@@ -69,12 +69,14 @@ int dx_attention_bwd(const float* qkv, int ld, const float* ctx, const float* dc
 /* bf16 = 1: QK^T / PV (and the five backward products) on v_mfma_f32_16x16x32_bf16, softmax and accumulation in fp32 */
 
 /* ---- dropout + residual + LayerNorm + FiLM + mask: model.py:188-191, :225-233, :256-258, :655-669 ------------------- */
-/* z = drop_pre(a) + res is written back over `a`; y = mask(film(drop_post(LN(z)))); C in {128, 1024} */
+/* z = drop_pre(a) + res is written back over `a`; y = mask(film(drop_post(LN(z)))); C in {128, 1024}.
+ * rows n >= lens[b] + halo are zero-filled and not computed: halo = 0 is the reference's padding mask, halo > 0 serves the
+ * unmasked prenet LayerNorms whose rows inside the conv halo are still needed */
 int dx_ln_fwd(float* a, const float* res, const float* w, const float* bias, const float* film, int ld_film,
-              const int* lens, float* y, float* mean, float* rstd, int B, int N, int C,
+              const int* lens, int halo, float* y, float* mean, float* rstd, int B, int N, int C,
               uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, void* stream);
 int dx_ln_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* w, const float* bias,
-              const float* film, int ld_film, const int* lens, float* dz, float* da, float* dw, float* dbias,
+              const float* film, int ld_film, const int* lens, int halo, float* dz, float* da, float* dw, float* dbias,
               float* dfilm, int ld_dfilm, int B, int N, int C, int relu_mask,
               uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, void* stream);
 

@@ -679,7 +679,7 @@ int dx_pack_weights(const float* W, void* fwd, void* bwd, int Cout, int Cin, int
 int dx_pack_weights_batched(const void* descs, int n, int bf16, void* stream) {
   DX_REQUIRE(descs && n > 0, "dx_pack_weights_batched: bad arguments");
   static_assert(sizeof(PackDesc) == 56, "PackDesc layout is part of the ABI");
-  dim3 grid(64, n);
+  dim3 grid(512, n);   // layers differ by 4 orders of magnitude in size: surplus blocks of the small ones exit at once
   if (bf16) hipLaunchKernelGGL(pack_weights_batched_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs);
   else hipLaunchKernelGGL(pack_weights_batched_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs);
   DX_LAUNCH_CHECK("dx_pack_weights_batched");

@@ -21,6 +21,7 @@ struct LnArgs {
   const float* w; const float* bias;   // LN affine [C]
   const float* film; int ld_film;      // [B][>=2C] gamma | beta, or null
   const int* lens;     // [B] or null (no mask)
+  int halo;            // rows n >= lens[b] + halo are padding nobody reads: zero-filled, not computed (halo 0 = the reference's mask)
   float* y;            // [rows][C]
   float* mean; float* rstd;            // [rows]
   int B, N;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
   const long rows = (long)a.B * a.N;
   for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
     const int b = (int)(row / a.N), n = (int)(row - (long)b * a.N);
-    const bool valid = !a.lens || n < a.lens[b];
+    const bool valid = !a.lens || n < a.lens[b] + a.halo;
     float z[E];
     if (!valid) {
       // padded row: the output is zero by definition and nothing reads z / mean / rstd of it (the backward skips it too);
@@ -122,7 +123,7 @@ struct LnBwdArgs {
   const float* z; const float* mean; const float* rstd;
   const float* w; const float* bias;
   const float* film; int ld_film;
-  const int* lens;
+  const int* lens; int halo;
   float* dz;           // [rows][C] gradient w.r.t. z (== residual branch gradient)
   float* da;           // [rows][C] gradient w.r.t. the pre-dropout GEMM output, or null (then dz serves)
   float* dw; float* dbias;             // [C] accumulated (atomics)
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
   const int b = blockIdx.y;
   const int n_begin = blockIdx.x * a.rows_per_block;
   const int n_end = min(a.N, n_begin + a.rows_per_block);
-  const int len_b = a.lens ? a.lens[b] : a.N;
+  const int len_b = a.lens ? a.lens[b] + a.halo : a.N;
   float gw[E], gb[E], gfg[E], gfb[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) gw[e] = gb[e] = gfg[e] = gfb[e] = 0.f;
@@ -488,14 +489,14 @@ inline int row_grid(long rows) { return (int)std::min<long>((rows + 3) / 4, 8192
 extern "C" {
 
 int dx_ln_fwd(float* a, const float* res, const float* w, const float* bias, const float* film, int ld_film,
-              const int* lens, float* y, float* mean, float* rstd, int B, int N, int C,
+              const int* lens, int halo, float* y, float* mean, float* rstd, int B, int N, int C,
               uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, void* stream) {
   DX_REQUIRE(a && w && bias && y && mean && rstd, "dx_ln_fwd: null pointer");
   DX_REQUIRE(C == 128 || C == 1024, "dx_ln_fwd: C must be 128 or 1024 (got %d)", C);
   DX_REQUIRE(B > 0 && N > 0, "dx_ln_fwd: bad dims");
   DX_REQUIRE(p_pre >= 0.f && p_pre < 1.f && p_post >= 0.f && p_post < 1.f, "dx_ln_fwd: dropout p out of range");
   DX_REQUIRE(!film || ld_film >= 2 * C, "dx_ln_fwd: ld_film too small");
-  LnArgs k{a, res, w, bias, film, ld_film, lens, y, mean, rstd, B, N,
+  LnArgs k{a, res, w, bias, film, ld_film, lens, halo, y, mean, rstd, B, N,
            seed_pre, (uint32_t)lrintf(p_pre * 65536.f), 1.f / (1.f - p_pre),
            seed_post, (uint32_t)lrintf(p_post * 65536.f), 1.f / (1.f - p_post)};
   hipStream_t s = (hipStream_t)stream;
@@ -509,14 +510,14 @@ int dx_ln_fwd(float* a, const float* res, const float* w, const float* bias, con
 }
 
 int dx_ln_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* w, const float* bias,
-              const float* film, int ld_film, const int* lens, float* dz, float* da, float* dw, float* dbias,
+              const float* film, int ld_film, const int* lens, int halo, float* dz, float* da, float* dw, float* dbias,
               float* dfilm, int ld_dfilm, int B, int N, int C, int relu_mask,
               uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, void* stream) {
   DX_REQUIRE(dy && z && mean && rstd && w && bias && dz && dw && dbias, "dx_ln_bwd: null pointer");
   DX_REQUIRE(C == 128 || C == 1024, "dx_ln_bwd: C must be 128 or 1024 (got %d)", C);
   DX_REQUIRE((film == nullptr) == (dfilm == nullptr), "dx_ln_bwd: film and dfilm must come together");
   const int rpb = 64;
-  LnBwdArgs k{dy, z, mean, rstd, w, bias, film, ld_film, lens, dz, da, dw, dbias, dfilm, ld_dfilm, B, N, rpb, relu_mask,
+  LnBwdArgs k{dy, z, mean, rstd, w, bias, film, ld_film, lens, halo, dz, da, dw, dbias, dfilm, ld_dfilm, B, N, rpb, relu_mask,
               seed_pre, (uint32_t)lrintf(p_pre * 65536.f), 1.f / (1.f - p_pre),
               seed_post, (uint32_t)lrintf(p_post * 65536.f), 1.f / (1.f - p_post)};
   hipStream_t s = (hipStream_t)stream;

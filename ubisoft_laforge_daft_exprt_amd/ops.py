@@ -255,19 +255,19 @@ def attention_bwd(qkv, ctx, dctx, lse, lens, heads, seed, p_drop):
     return dqkv
 
 
-def ln_fwd(a, res, w, b, film, lens, *, seed_pre=0, p_pre=0.0, seed_post=0, p_post=0.0):
+def ln_fwd(a, res, w, b, film, lens, *, seed_pre=0, p_pre=0.0, seed_post=0, p_post=0.0, halo=0):
     """In place on ``a`` (becomes z = drop(a) + res).  Returns (y, mean, rstd)."""
     B, N, C = a.shape
     y = torch.empty_like(a)
     mean = torch.empty(B, N, dtype=torch.float32, device=a.device)
     rstd = torch.empty(B, N, dtype=torch.float32, device=a.device)
-    lib().dx_ln_fwd(_p(a), _p(res), _p(w), _p(b), _p(film), 0 if film is None else film.stride(0), _p(lens), _p(y), _p(mean), _p(rstd),
+    lib().dx_ln_fwd(_p(a), _p(res), _p(w), _p(b), _p(film), 0 if film is None else film.stride(0), _p(lens), int(halo), _p(y), _p(mean), _p(rstd),
                     B, N, C, seed_pre, float(p_pre), seed_post, float(p_post), _stream())
     return y, mean, rstd
 
 
 def ln_bwd(dy, z, mean, rstd, w, b, film, lens, *, relu_mask=False, want_da=False, seed_pre=0, p_pre=0.0, seed_post=0, p_post=0.0,
-           arena=None, w_sink=None, b_sink=None):
+           arena=None, w_sink=None, b_sink=None, halo=0):
     """Returns (dz, da or None, dw, db, dfilm or None); dw/db are None when accumulated straight into the given sinks."""
     B, N, C = z.shape
     dz = torch.empty_like(z)
@@ -275,7 +275,7 @@ def ln_bwd(dy, z, mean, rstd, w, b, film, lens, *, relu_mask=False, want_da=Fals
     dw = w_sink if w_sink is not None else _zeros(arena, C, device=z.device)
     db = b_sink if b_sink is not None else _zeros(arena, C, device=z.device)
     dfilm = _zeros(arena, B, 2 * C, device=z.device) if film is not None else None
-    lib().dx_ln_bwd(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(film), 0 if film is None else film.stride(0), _p(lens),
+    lib().dx_ln_bwd(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(film), 0 if film is None else film.stride(0), _p(lens), int(halo),
                     _p(dz), _p(da), _p(dw), _p(db), _p(dfilm), 2 * C, B, N, C, int(relu_mask),
                     seed_pre, float(p_pre), seed_post, float(p_post), _stream())
     return dz, da, (None if w_sink is not None else dw), (None if b_sink is not None else db), dfilm
