@@ -206,11 +206,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
     if (co >= a.Cout) continue;
     const bool full = (co + 3 < a.Cout);
     float bv[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (full) {                                          // one 16-byte load per epilogue vector instead of four scalar ones
+      if (a.bias) { const float4 t = *reinterpret_cast<const float4*>(a.bias + co); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[3] = t.w; }
+      if (a.post_scale) {
+        const float4 t = *reinterpret_cast<const float4*>(a.post_scale + co), u = *reinterpret_cast<const float4*>(a.post_shift + co);
+        sc[0] = t.x; sc[1] = t.y; sc[2] = t.z; sc[3] = t.w; sh[0] = u.x; sh[1] = u.y; sh[2] = u.z; sh[3] = u.w;
+      }
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (co + e < a.Cout) {
-        if (a.bias) bv[e] = a.bias[co + e];
-        if (a.post_scale) { sc[e] = a.post_scale[co + e]; sh[e] = a.post_shift[co + e]; }
+      for (int e = 0; e < 4; ++e) {
+        if (co + e < a.Cout) {
+          if (a.bias) bv[e] = a.bias[co + e];
+          if (a.post_scale) { sc[e] = a.post_scale[co + e]; sh[e] = a.post_shift[co + e]; }
+        }
       }
     }
 #pragma unroll
