@@ -326,7 +326,6 @@ class DaftExprt(nn.Module):
         self.gaussian_upsampling = GaussianUpsamplingModule(hparams)
         self.frame_decoder = FrameDecoder(hparams, is_training=is_training)
         self.spk_projection = LinearNorm(getattr(hparams, 'external_emb_dim', 192), self.hidden_embed_dim)
-        self._host_lengths = {}
 
     # -- batch plumbing ------------------------------------------------------------------------------------------------
     def parse_batch(self, device, batch):
@@ -346,16 +345,17 @@ class DaftExprt(nn.Module):
         durations_float, symbols_energy, symbols_pitch = (to(t, torch.float32) for t in (durations_float, symbols_energy, symbols_pitch))
         input_lengths, output_lengths, speaker_ids = (to(t, torch.long) for t in (input_lengths, output_lengths, speaker_ids))
         frames_energy, frames_pitch, mel_specs = (to(t, torch.float32) for t in (frames_energy, frames_pitch, mel_specs))
-        if host:
-            self._host_lengths = {id(input_lengths): host['in'], id(output_lengths): host['out']}
-            self._host_keepalive = (input_lengths, output_lengths)
+        if host:                                   # ride along on the tensor objects themselves (no global cache to go stale)
+            input_lengths._dx_host_lengths = host['in']
+            output_lengths._dx_host_lengths = host['out']
         inputs = (symbols, durations_float, durations_int, symbols_energy, symbols_pitch, input_lengths,
                   frames_energy, frames_pitch, mel_specs, output_lengths, speaker_ids, spk_embs)
         targets = (durations_float, symbols_energy, symbols_pitch, mel_specs, output_lengths, speaker_ids)
         return inputs, targets
 
-    def _lengths(self, t):
-        return Lengths(t, host=self._host_lengths.get(id(t)))
+    @staticmethod
+    def _lengths(t):
+        return Lengths(t, host=getattr(t, '_dx_host_lengths', None))
 
     @staticmethod
     def _require_gpu(t):
