@@ -273,6 +273,256 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
 #undef DX_STORE_CHUNK
 
 // ------------------------------------------------------------------------------------------------
+// Weight-stationary persistent variant for the short-K layers (Cin <= 128: MHA in/out projections, FF conv1 and the input
+// gradient of FF conv2, mel projection, prenet conv0), bf16 operands.
+// With K = TAPS*128 the tiled kernel above runs only two pipeline stages per workgroup, and ~60 % of a workgroup's life is
+// fixed cost (first loads -> LDS -> fragments -> epilogue).  Here a 512-thread workgroup (8 waves, one per CU for TAPS=3)
+// keeps its whole weight slice [2 chunks][TAPS][128 co][64 ci] (96 KB) in LDS for its lifetime and walks over token tiles
+// (stride = workgroups per channel tile); the next tile's activations are prefetched into registers during the MFMAs.
+// ------------------------------------------------------------------------------------------------
+template <int TAPS>
+__global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, int wgs_per_cotile) {
+  constexpr int PAD = (TAPS - 1) / 2;
+  constexpr int TOK = 128;
+  constexpr int XROWS = TOK + TAPS - 1;
+  constexpr int XU = 32;                                   // 16-byte fp32 units per activation row (128 channels)
+  constexpr int X_IT = (XROWS * XU + 511) / 512;
+  constexpr int W_ROWS = 2 * TAPS * TILE;                  // [chunk][tap][co]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ws = smem;
+  unsigned char* Xs = smem + W_ROWS * 128;                 // [chunk][XROWS] rows of 128 bytes; re-used as the output staging tile
+  constexpr int OLD = 288;                                 // output staging row stride (bytes): 128 bf16 + pad
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave >> 1, wt = wave & 1;                 // 4 x 2 waves: 32 channels x 64 tokens each
+  const int r = lane & 15, g = lane >> 4;
+  const int co0 = blockIdx.y * TILE;
+  const __bf16* Wp = reinterpret_cast<const __bf16*>(a.Wp);
+
+  // weight slice -> LDS, once
+  for (int u = tid; u < W_ROWS * 8; u += 512) {
+    const int row = u >> 3, q = u & 7;
+    const int ch = row / (TAPS * TILE), rem = row - ch * (TAPS * TILE);
+    const int tap = rem >> 7, col = rem & (TILE - 1);
+    *reinterpret_cast<f32x4*>(Ws + lds_off(row, q)) =
+        *reinterpret_cast<const f32x4*>(Wp + ((size_t)(tap * a.CoutP + co0 + col) * a.CinP + ch * 64) + q * 8);
+  }
+
+  const int tiles_n = (a.N + TOK - 1) / TOK;
+  const int total = a.B * tiles_n;
+  f32x4 xreg[X_IT];
+#define DX_WS_LOAD(B_, N0_)                                                                                          \
+  _Pragma("unroll") for (int it = 0; it < X_IT; ++it) {                                                              \
+    const int u = tid + it * 512;                                                                                    \
+    const int row = u / XU, q = u % XU;                                                                              \
+    const int n = (N0_) + row - PAD, ci = q * 4;                                                                     \
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                                             \
+    if (u < XROWS * XU && n >= 0 && n < a.N && ci < a.Cin) v = *reinterpret_cast<const f32x4*>(a.X + ((size_t)(B_) * a.N + n) * a.ldx + ci); \
+    xreg[it] = v;                                                                                                    \
+  }
+  // next live tile of this workgroup (padding tiles beyond the halo are zero-filled on the way)
+  auto next_tile = [&](int& t, int& b, int& n0) {
+    for (; t < total; t += wgs_per_cotile) {
+      b = t / tiles_n;
+      n0 = (t - b * tiles_n) * TOK;
+      if (!(a.skip_halo >= 0 && n0 >= a.lens[b] + a.skip_halo)) return true;
+      if (!a.accumulate) {
+        for (int u = tid; u < TOK * 32; u += 512) {
+          const int row = u >> 5, q = u & 31;
+          const int n = n0 + row, co = co0 + q * 4;
+          if (n < a.N && co < a.Cout) {
+            if (a.y_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.Y) + ((size_t)b * a.N + n) * a.ldy + co) = make_uint2(0u, 0u);
+            else {
+              float* dst = a.Y + ((size_t)b * a.N + n) * a.ldy + co;
+              if (co + 3 < a.Cout) *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+              else for (int e = 0; co + e < a.Cout; ++e) dst[e] = 0.f;
+            }
+          }
+        }
+      }
+    }
+    return false;
+  };
+
+  int t = blockIdx.x, b = 0, n0 = 0;
+  bool live = next_tile(t, b, n0);
+  if (live) DX_WS_LOAD(b, n0)
+  while (live) {
+    const int cb = b, cn0 = n0;
+    __syncthreads();                                       // previous tile's fragment reads are done (and W is in place)
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+      const int u = tid + it * 512;
+      const int row = u / XU, q = u % XU;                  // q: float4 index 0..31 -> chunk q>>4, 8-byte slot (q&15)
+      if (u < XROWS * XU)
+        *reinterpret_cast<uint2*>(Xs + (q >> 4) * (XROWS * 128) + lds_off(row, (q & 15) >> 1) + ((q & 1) << 3)) = pack_bf16x4v(xreg[it]);
+    }
+    __syncthreads();
+    t += wgs_per_cotile;
+    live = next_tile(t, b, n0);
+    if (live) DX_WS_LOAD(b, n0)
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          float4 wf[2], xf[4];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            wf[i] = *reinterpret_cast<const float4*>(Ws + lds_off((ch * TAPS + tap) * TILE + wc * 32 + i * 16 + r, ks * 4 + g));
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            xf[j] = *reinterpret_cast<const float4*>(Xs + ch * (XROWS * 128) + lds_off(wt * 64 + j * 16 + r + tap, ks * 4 + g));
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Mma<__bf16>::run(wf[i], xf[j], acc[i][j]);
+        }
+
+    const int len_b = a.lens ? a.lens[cb] : a.N;
+    if (a.y_bf16) {
+      // bf16 outputs (the 1024-wide hidden tensors): row-per-lane 8-byte global stores are store-issue bound, so the tile goes
+      // through LDS and leaves as fully coalesced 16-byte row segments; ReLU-mask / padding mask are applied on the way out
+      __syncthreads();                                     // every wave has finished reading the activation tile
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int cl = wc * 32 + i * 16 + g * 4;
+        const int co = co0 + cl;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+        if (co < a.Cout) {                                 // bf16 outputs have Cout % 4 == 0
+          if (a.bias) { const float4 tb = *reinterpret_cast<const float4*>(a.bias + co); bv[0] = tb.x; bv[1] = tb.y; bv[2] = tb.z; bv[3] = tb.w; }
+          if (a.post_scale) {
+            const float4 ts = *reinterpret_cast<const float4*>(a.post_scale + co), tsh = *reinterpret_cast<const float4*>(a.post_shift + co);
+            sc[0] = ts.x; sc[1] = ts.y; sc[2] = ts.z; sc[3] = ts.w; sh[0] = tsh.x; sh[1] = tsh.y; sh[2] = tsh.z; sh[3] = tsh.w;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float tv = acc[i][j][e] + bv[e];
+            if (a.relu) tv = fmaxf(tv, 0.f);
+            v[e] = (tv * sc[e] + sh[e]) * a.out_scale;
+          }
+          *reinterpret_cast<uint2*>(Xs + (wt * 64 + j * 16 + r) * OLD + cl * 2) = pack_bf16x4(make_float4(v[0], v[1], v[2], v[3]));
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int u = tid + it * 512;
+        const int row = u >> 4, q = u & 15;
+        const int n = cn0 + row, co = co0 + q * 8;
+        if (n < a.N && co < a.Cout) {
+          bf16x8 o = *reinterpret_cast<const bf16x8*>(Xs + row * OLD + q * 16);
+          const size_t grow = (size_t)cb * a.N + n;
+          if (a.relu_aux) {
+            if (a.aux_bf16) {
+              const bf16x8 av = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.relu_aux) + grow * a.ld_aux + co);
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                if (!((float)av[e] > 0.f)) o[e] = (__bf16)0.f;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                if (!(a.relu_aux[grow * a.ld_aux + co + e] > 0.f)) o[e] = (__bf16)0.f;
+            }
+          }
+          if (a.mask_rows && n >= len_b) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)0.f;
+          }
+          if (co + 7 < a.Cout) *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(a.Y) + grow * a.ldy + co) = o;
+          else *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.Y) + grow * a.ldy + co) = bf16x4{o[0], o[1], o[2], o[3]};
+        }
+      }
+      continue;                                            // the loop-top barrier orders these LDS reads before the next tile's stores
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int co = co0 + wc * 32 + i * 16 + g * 4;
+      if (co >= a.Cout) continue;
+      const bool full = (co + 3 < a.Cout);
+      float bv[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (co + e < a.Cout) {
+          if (a.bias) bv[e] = a.bias[co + e];
+          if (a.post_scale) { sc[e] = a.post_scale[co + e]; sh[e] = a.post_shift[co + e]; }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = cn0 + wt * 64 + j * 16 + r;
+        if (n >= a.N) continue;
+        const size_t row = (size_t)cb * a.N + n;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float tv = acc[i][j][e] + bv[e];
+          if (a.relu) tv = fmaxf(tv, 0.f);
+          tv = tv * sc[e] + sh[e];
+          v[e] = tv * a.out_scale;
+        }
+        if (a.relu_aux) {
+          if (a.aux_bf16) {
+            const bf16x4 av = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.relu_aux) + row * a.ld_aux + co);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (!((float)av[e] > 0.f)) v[e] = 0.f;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (co + e < a.Cout && !(a.relu_aux[row * a.ld_aux + co + e] > 0.f)) v[e] = 0.f;
+          }
+        }
+        if (a.mask_rows && n >= len_b) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+        if (a.y_bf16) {
+          *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.Y) + row * a.ldy + co) = pack_bf16x4(make_float4(v[0], v[1], v[2], v[3]));
+          continue;
+        }
+        float* dst = a.Y + row * a.ldy + co;
+        if (full) {
+          float4 o = make_float4(v[0], v[1], v[2], v[3]);
+          if (a.accumulate) {
+            const float4 old = *reinterpret_cast<const float4*>(dst);
+            o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+          }
+          *reinterpret_cast<float4*>(dst) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < a.Cout) dst[e] = a.accumulate ? dst[e] + v[e] : v[e];
+        }
+      }
+    }
+  }
+#undef DX_WS_LOAD
+}
+
+template <int TAPS>
+void launch_conv_ws(const ConvGemmArgs& a, hipStream_t s) {
+  const size_t smem = (size_t)(2 * TAPS * TILE) * 128 + std::max<size_t>((size_t)2 * (128 + TAPS - 1) * 128, (size_t)128 * 288);
+  static bool configured = false;
+  if (!configured) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    configured = true;
+  }
+  const int co_tiles = a.CoutP / TILE;
+  const int total = a.B * dx_cdiv(a.N, 128);
+  const int per_cu = smem * 2 <= 160 * 1024 ? 2 : 1;       // TAPS=1 fits twice per CU
+  const int wgs = std::max(1, std::min(total, (256 * per_cu) / co_tiles));
+  hipLaunchKernelGGL((conv_ws_kernel<TAPS>), dim3(wgs, co_tiles), dim3(512), smem, s, a, wgs);
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight gradient: G[tap][co][ci] += sum over tokens of dY[token][co] * X[token + tap - PAD][ci]
 // Both operands are token-major in HBM, i.e. K-major; they are staged untransposed ([token][channel],
 // row stride 132 floats) and fragments are gathered with four ds_read_b32 per operand (conflict free:
@@ -722,7 +972,10 @@ int dx_conv_gemm(const void* Xv, int ldx, const void* Wp, const float* bias, voi
                  relu_aux, ld_aux, accumulate, lens, mask_rows, out_scale, skip_halo, x_bf16, y_bf16, aux_bf16};
   hipStream_t s = (hipStream_t)stream;
   dx_prof_begin(DX_PROF_CONV_GEMM, s);
-  if (bf16) { if (taps == 3) launch_conv<__bf16, 3>(a, s); else launch_conv<__bf16, 1>(a, s); }
+  static const int use_ws = getenv("DX_CONV_WS") ? atoi(getenv("DX_CONV_WS")) : 1;
+  if (bf16 && use_ws && d[1] == 128 && !x_bf16 && (long)B * dx_cdiv(N, 128) >= 64) {      // short-K layers: weight-stationary persistent kernel
+    if (taps == 3) launch_conv_ws<3>(a, s); else launch_conv_ws<1>(a, s);
+  } else if (bf16) { if (taps == 3) launch_conv<__bf16, 3>(a, s); else launch_conv<__bf16, 1>(a, s); }
   else      { if (taps == 3) launch_conv<float, 3>(a, s);  else launch_conv<float, 1>(a, s); }
   dx_prof_end(DX_PROF_CONV_GEMM, s);
   DX_LAUNCH_CHECK("dx_conv_gemm");
