@@ -126,6 +126,42 @@ def test_bf16_hidden_storage(ops):
         ops.set_precision('f32')
 
 
+@pytest.mark.parametrize('Cin,Cout,taps', [(128, 1024, 3), (128, 384, 1), (128, 128, 1), (80, 1024, 3), (128, 80, 1)])
+def test_weight_stationary_conv_path(ops, Cin, Cout, taps):
+    """bf16 layers with Cin <= 128 and >= 64 token tiles run the persistent weight-stationary kernel: check it against the tiled
+    kernel (DX_CONV_WS is read once per process, so the reference here is PyTorch) for every epilogue variant."""
+    ops.set_precision('bf16')
+    try:
+        B, N = 9, 1000                                       # 9 x 8 = 72 token tiles, ragged last tile
+        lens = lens_tensor([1000, 999, 897, 896, 640, 513, 129, 128, 1])
+        wshape = (Cout, Cin, 3) if taps == 3 else (Cout, Cin)
+        w = randn(*wshape, seed=1, scale=1.0 / math.sqrt(Cin * taps))
+        b = randn(Cout, seed=2, scale=0.1)
+        x = randn(B, N, Cin, seed=3)
+        pack = ops.PackedWeight(w)
+        ref = ref_conv(x, w, b, taps)
+        assert rel_err(ops.conv_gemm(x, pack, b), ref) < 2e-2
+        valid = (torch.arange(N, device=DEV)[None, :] < lens[:, None])[:, :, None]
+        y = ops.conv_gemm(x, pack, b, lens=lens, mask_rows=True, halo=0)
+        assert rel_err(y, ref * valid) < 2e-2 and torch.equal(y * ~valid, torch.zeros_like(y))
+        if Cout % 8 == 0:
+            aux = randn(B, N, Cout, seed=4).to(torch.bfloat16)
+            sc, sh = 1 + 0.1 * randn(Cout, seed=5), torch.zeros(Cout, device=DEV)
+            yb = ops.conv_gemm(x, pack, b, relu=True, post_scale=sc, post_shift=sh, relu_aux=aux, lens=lens, halo=1, out_dtype=torch.bfloat16,
+                               out_scale=0.5)
+            refb = (F.relu(ref) * sc) * 0.5 * (aux.float() > 0)
+            keep = (torch.arange(N, device=DEV)[None, :, None] < ((lens[:, None, None] + 1 + 127) // 128) * 128)   # whole tiles inside len+halo
+            assert yb.dtype == torch.bfloat16 and rel_err(yb.float() * keep, refb * keep) < 2e-2
+            assert torch.equal(yb.float() * ~keep, torch.zeros_like(refb))
+        acc0 = randn(B, N, Cout, seed=6)
+        ya = ops.conv_gemm(x, pack, None, out=acc0.clone(), accumulate=True, lens=lens, halo=0)
+        tiles_ok = (torch.arange(N, device=DEV)[None, :, None] < ((lens[:, None, None] + 127) // 128) * 128)
+        assert rel_err(ya * tiles_ok, (acc0 + ref_conv(x, w, None, taps)) * tiles_ok) < 2e-2
+        assert torch.equal(ya * ~tiles_ok, acc0 * ~tiles_ok)               # skipped tiles are left untouched when accumulating
+    finally:
+        ops.set_precision('f32')
+
+
 def ref_attention(qkv, lens, heads, keep=None, p=0.0):
     B, N, D3 = qkv.shape
     D = D3 // 3
