@@ -317,6 +317,29 @@ def test_layernorm_dropout_and_relu_mask(ops):
     assert rel_err(dz2, x.grad * (x.detach() > 0)) < 1e-5
 
 
+def test_layernorm_1024_bf16_rows(ops):
+    """bf16-stored 1024-wide rows (prenet, bf16 mode): ReLU'd input -> LayerNorm -> dropout, halo skipping, and the backward."""
+    B, N, C, p = 3, 70, 1024, 0.1
+    lens = lens_tensor([70, 40, 12])
+    x = F.relu(randn(B, N, C, seed=1)).to(torch.bfloat16)
+    w, b = 1 + 0.1 * randn(C, seed=2), randn(C, seed=3, scale=0.1)
+    xk = x.clone()
+    y, mean, rstd = ops.ln_fwd(xk, None, w, b, None, lens, seed_post=9, p_post=p, halo=2)
+    assert y.dtype == torch.bfloat16 and torch.equal(xk, x)
+    xf = x.float().requires_grad_(True)
+    ln = F.layer_norm(xf, (C,), w, b, 1e-5)
+    live = (torch.arange(N, device=DEV)[None, :] < (lens + 2)[:, None])[:, :, None]
+    keep = torch.where(live, (y.float() / ln.detach() * (1 - p)).round().clamp(0, 1), torch.ones_like(ln))
+    assert abs(keep[live.expand_as(keep)].mean().item() - (1 - p)) < 0.02
+    ref = ln * keep / (1 - p) * live
+    assert rel_err(y.float(), ref.detach()) < 1e-2 and torch.equal(y.float() * ~live, torch.zeros_like(ref))
+    dy = (randn(B, N, C, seed=4) * live).to(torch.bfloat16)
+    ref.backward(dy.float())
+    dz, _, dw, db, _ = ops.ln_bwd(dy, xk, mean, rstd, w, b, None, lens, relu_mask=True, seed_post=9, p_post=p, halo=2)
+    assert dz.dtype == torch.bfloat16
+    assert rel_err(dz.float(), xf.grad * (x.float() > 0)) < 2e-2
+
+
 def test_embedding_positions_masks_pool(ops):
     from oracle import daft_exprt_oracle as oracle
     B, N, D = 3, 21, 128

@@ -60,14 +60,37 @@ __device__ __forceinline__ void row_store(float* p, int lane, const float v[RowV
     else *reinterpret_cast<float2*>(p + c) = make_float2(v[k * 2], v[k * 2 + 1]);
   }
 }
+// bf16-stored rows (the 1024-wide prenet activations in bf16 operand mode): same lane -> column map, 8-byte accesses
+template <int C>
+__device__ __forceinline__ void row_load(const __bf16* p, int lane, float v[RowVec<C>::K * RowVec<C>::V]) {
+  static_assert(RowVec<C>::V == 4, "bf16 rows need C >= 256");
+#pragma unroll
+  for (int k = 0; k < RowVec<C>::K; ++k) {
+    const bf16x4 t = *reinterpret_cast<const bf16x4*>(p + (k * 64 + lane) * 4);
+    v[k * 4 + 0] = (float)t[0]; v[k * 4 + 1] = (float)t[1]; v[k * 4 + 2] = (float)t[2]; v[k * 4 + 3] = (float)t[3];
+  }
+}
+template <int C>
+__device__ __forceinline__ void row_store(__bf16* p, int lane, const float v[RowVec<C>::K * RowVec<C>::V]) {
+  static_assert(RowVec<C>::V == 4, "bf16 rows need C >= 256");
+#pragma unroll
+  for (int k = 0; k < RowVec<C>::K; ++k) {
+    bf16x4 t;
+    t[0] = (__bf16)v[k * 4]; t[1] = (__bf16)v[k * 4 + 1]; t[2] = (__bf16)v[k * 4 + 2]; t[3] = (__bf16)v[k * 4 + 3];
+    *reinterpret_cast<bf16x4*>(p + (k * 64 + lane) * 4) = t;
+  }
+}
 template <int C> __device__ __forceinline__ int row_col(int lane, int idx) {
   constexpr int V = RowVec<C>::V;
   return ((idx / V) * 64 + lane) * V + (idx % V);
 }
 
-template <int C>
+template <int C, typename IO>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
   constexpr int E = RowVec<C>::K * RowVec<C>::V;
+  IO* const A = reinterpret_cast<IO*>(a.a);
+  const IO* const R = reinterpret_cast<const IO*>(a.res);
+  IO* const Y = reinterpret_cast<IO*>(a.y);
   const int lane = threadIdx.x & 63;
   const long rows = (long)a.B * a.N;
   for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
@@ -79,23 +102,23 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
       // keep them defined without touching the inputs
 #pragma unroll
       for (int e = 0; e < E; ++e) z[e] = 0.f;
-      row_store<C>(a.y + row * C, lane, z);
-      if (a.thresh_pre || a.res) row_store<C>(a.a + row * C, lane, z);
+      row_store<C>(Y + row * C, lane, z);
+      if (a.thresh_pre || a.res) row_store<C>(A + row * C, lane, z);
       if (lane == 0) { a.mean[row] = 0.f; a.rstd[row] = 0.f; }
       continue;
     }
-    row_load<C>(a.a + row * C, lane, z);
+    row_load<C>(A + row * C, lane, z);
     if (a.thresh_pre) {
 #pragma unroll
       for (int e = 0; e < E; ++e) z[e] *= dx_dropout_scale(a.seed_pre, (uint64_t)row * C + row_col<C>(lane, e), a.thresh_pre, a.inv_keep_pre);
     }
     if (a.res) {
       float rv[E];
-      row_load<C>(a.res + row * C, lane, rv);
+      row_load<C>(R + row * C, lane, rv);
 #pragma unroll
       for (int e = 0; e < E; ++e) z[e] += rv[e];
     }
-    if (a.thresh_pre || a.res) row_store<C>(a.a + row * C, lane, z);
+    if (a.thresh_pre || a.res) row_store<C>(A + row * C, lane, z);
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < E; ++e) s += z[e];
@@ -114,7 +137,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
       if (a.film) t = a.film[(size_t)b * a.ld_film + c] * t + a.film[(size_t)b * a.ld_film + C + c];
       y[e] = valid ? t : 0.f;
     }
-    row_store<C>(a.y + row * C, lane, y);
+    row_store<C>(Y + row * C, lane, y);
   }
 }
 
@@ -135,9 +158,13 @@ struct LnBwdArgs {
 };
 
 // grid: (blocks per batch row, B); each wave walks rows of ONE batch row so FiLM gradients reduce per b.
-template <int C>
+template <int C, typename IO>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
   constexpr int E = RowVec<C>::K * RowVec<C>::V;
+  const IO* const DY = reinterpret_cast<const IO*>(a.dy);
+  const IO* const Z = reinterpret_cast<const IO*>(a.z);
+  IO* const DZ = reinterpret_cast<IO*>(a.dz);
+  IO* const DA = reinterpret_cast<IO*>(a.da);
   __shared__ float red[4][C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y;
@@ -160,13 +187,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
     if (n >= len_b) {
 #pragma unroll
       for (int e = 0; e < E; ++e) dzv[e] = 0.f;
-      row_store<C>(a.dz + row * C, lane, dzv);
-      if (a.da) row_store<C>(a.da + row * C, lane, dzv);
+      row_store<C>(DZ + row * C, lane, dzv);
+      if (a.da) row_store<C>(DA + row * C, lane, dzv);
       continue;
     }
     float dy[E], z[E];
-    row_load<C>(a.dy + row * C, lane, dy);
-    row_load<C>(a.z + row * C, lane, z);
+    row_load<C>(DY + row * C, lane, dy);
+    row_load<C>(Z + row * C, lane, z);
     const float mu = a.mean[row], rs = a.rstd[row];
     float s1 = 0.f, s2 = 0.f, g[E], xh[E];
 #pragma unroll
@@ -190,13 +217,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
       dzv[e] = rs * (g[e] - s1 - xh[e] * s2);
       if (a.relu_mask && !(z[e] > 0.f)) dzv[e] = 0.f;
     }
-    row_store<C>(a.dz + row * C, lane, dzv);
+    row_store<C>(DZ + row * C, lane, dzv);
     if (a.da) {
       if (a.thresh_pre) {
 #pragma unroll
         for (int e = 0; e < E; ++e) dzv[e] *= dx_dropout_scale(a.seed_pre, (uint64_t)row * C + row_col<C>(lane, e), a.thresh_pre, a.inv_keep_pre);
       }
-      row_store<C>(a.da + row * C, lane, dzv);
+      row_store<C>(DA + row * C, lane, dzv);
     }
   }
   // block reduction of the per-channel sums, then one atomic per channel per block
@@ -488,10 +515,12 @@ inline int row_grid(long rows) { return (int)std::min<long>((rows + 3) / 4, 8192
 
 extern "C" {
 
-int dx_ln_fwd(float* a, const float* res, const float* w, const float* bias, const float* film, int ld_film,
-              const int* lens, int halo, float* y, float* mean, float* rstd, int B, int N, int C,
-              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, void* stream) {
+int dx_ln_fwd(void* av, const void* resv, const float* w, const float* bias, const float* film, int ld_film,
+              const int* lens, int halo, void* yv, float* mean, float* rstd, int B, int N, int C,
+              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, int io_bf16, void* stream) {
+  float* a = (float*)av; const float* res = (const float*)resv; float* y = (float*)yv;
   DX_REQUIRE(a && w && bias && y && mean && rstd, "dx_ln_fwd: null pointer");
+  DX_REQUIRE(!io_bf16 || C == 1024, "dx_ln_fwd: bf16 rows are supported for C = 1024 only");
   DX_REQUIRE(C == 128 || C == 1024, "dx_ln_fwd: C must be 128 or 1024 (got %d)", C);
   DX_REQUIRE(B > 0 && N > 0, "dx_ln_fwd: bad dims");
   DX_REQUIRE(p_pre >= 0.f && p_pre < 1.f && p_post >= 0.f && p_post < 1.f, "dx_ln_fwd: dropout p out of range");
@@ -502,17 +531,20 @@ int dx_ln_fwd(float* a, const float* res, const float* w, const float* bias, con
   hipStream_t s = (hipStream_t)stream;
   dx_prof_begin(DX_PROF_ROWS, s);
   const int grid = row_grid((long)B * N);
-  if (C == 128) hipLaunchKernelGGL(ln_fwd_kernel<128>, dim3(grid), dim3(256), 0, s, k);
-  else hipLaunchKernelGGL(ln_fwd_kernel<1024>, dim3(grid), dim3(256), 0, s, k);
+  if (C == 128) hipLaunchKernelGGL((ln_fwd_kernel<128, float>), dim3(grid), dim3(256), 0, s, k);
+  else if (io_bf16) hipLaunchKernelGGL((ln_fwd_kernel<1024, __bf16>), dim3(grid), dim3(256), 0, s, k);
+  else hipLaunchKernelGGL((ln_fwd_kernel<1024, float>), dim3(grid), dim3(256), 0, s, k);
   dx_prof_end(DX_PROF_ROWS, s);
   DX_LAUNCH_CHECK("dx_ln_fwd");
   return DX_OK;
 }
 
-int dx_ln_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* w, const float* bias,
-              const float* film, int ld_film, const int* lens, int halo, float* dz, float* da, float* dw, float* dbias,
+int dx_ln_bwd(const void* dyv, const void* zv, const float* mean, const float* rstd, const float* w, const float* bias,
+              const float* film, int ld_film, const int* lens, int halo, void* dzv, void* dav, float* dw, float* dbias,
               float* dfilm, int ld_dfilm, int B, int N, int C, int relu_mask,
-              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, void* stream) {
+              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, int io_bf16, void* stream) {
+  const float* dy = (const float*)dyv; const float* z = (const float*)zv; float* dz = (float*)dzv; float* da = (float*)dav;
+  DX_REQUIRE(!io_bf16 || C == 1024, "dx_ln_bwd: bf16 rows are supported for C = 1024 only");
   DX_REQUIRE(dy && z && mean && rstd && w && bias && dz && dw && dbias, "dx_ln_bwd: null pointer");
   DX_REQUIRE(C == 128 || C == 1024, "dx_ln_bwd: C must be 128 or 1024 (got %d)", C);
   DX_REQUIRE((film == nullptr) == (dfilm == nullptr), "dx_ln_bwd: film and dfilm must come together");
@@ -523,8 +555,9 @@ int dx_ln_bwd(const float* dy, const float* z, const float* mean, const float* r
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(dx_cdiv(N, rpb), B);
   dx_prof_begin(DX_PROF_ROWS, s);
-  if (C == 128) hipLaunchKernelGGL(ln_bwd_kernel<128>, grid, dim3(256), 0, s, k);
-  else hipLaunchKernelGGL(ln_bwd_kernel<1024>, grid, dim3(256), 0, s, k);
+  if (C == 128) hipLaunchKernelGGL((ln_bwd_kernel<128, float>), grid, dim3(256), 0, s, k);
+  else if (io_bf16) hipLaunchKernelGGL((ln_bwd_kernel<1024, __bf16>), grid, dim3(256), 0, s, k);
+  else hipLaunchKernelGGL((ln_bwd_kernel<1024, float>), grid, dim3(256), 0, s, k);
   dx_prof_end(DX_PROF_ROWS, s);
   DX_LAUNCH_CHECK("dx_ln_bwd");
   return DX_OK;

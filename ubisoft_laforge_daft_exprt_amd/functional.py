@@ -202,9 +202,10 @@ class AccentFrontFn(torch.autograd.Function):
         seeds = [next_seed() if training else 0 for _ in range(3)]
         x0 = ops.transpose(mel.contiguous())                                   # (B, T, n_mel) channels-last
         L = lens.i32
-        h0 = ops.conv_gemm(x0, packs['p0'], c0_b, relu=True, lens=L, halo=2)   # three stacked k=3 convs: halos 2, 1, 0
+        hd = ops.hidden_dtype()                                               # 1024-wide tensors: bf16 in bf16 operand mode
+        h0 = ops.conv_gemm(x0, packs['p0'], c0_b, relu=True, lens=L, halo=2, out_dtype=hd)   # three stacked k=3 convs: halos 2, 1, 0
         y0, m0, r0 = ops.ln_fwd(h0, None, l0_w, l0_b, None, L, seed_post=seeds[0], p_post=p, halo=2)
-        h1 = ops.conv_gemm(y0, packs['p1'], c1_b, relu=True, lens=L, halo=1)
+        h1 = ops.conv_gemm(y0, packs['p1'], c1_b, relu=True, lens=L, halo=1, out_dtype=hd)
         y1, m1, r1 = ops.ln_fwd(h1, None, l1_w, l1_b, None, L, seed_post=seeds[1], p_post=p, halo=1)
         h2 = ops.conv_gemm(y1, packs['p2'], c2_b, relu=True, lens=L, halo=0)
         y2, m2, r2 = ops.ln_fwd(h2, None, l2_w, l2_b, None, L, seed_post=seeds[2], p_post=p, halo=0)
@@ -227,11 +228,11 @@ class AccentFrontFn(torch.autograd.Function):
         dz2, _, dl2_w, dl2_b, _ = ops.ln_bwd(dout, h2, m2, r2, l2_w, l2_b, None, L, relu_mask=True, seed_post=seeds[2], p_post=p,
                                               w_sink=g('l2_w'), b_sink=g('l2_b'), halo=0)
         dc2_w, dc2_b = ops.conv_wgrad(dz2, y1, packs['p2'], L, 0, w_sink=g('c2_w'), b_sink=g('c2_b'))
-        dy1 = ops.conv_gemm(dz2, packs['p2'], None, transpose=True, lens=L, halo=1)
+        dy1 = ops.conv_gemm(dz2, packs['p2'], None, transpose=True, lens=L, halo=1, out_dtype=h1.dtype)
         dz1, _, dl1_w, dl1_b, _ = ops.ln_bwd(dy1, h1, m1, r1, l1_w, l1_b, None, L, relu_mask=True, seed_post=seeds[1], p_post=p,
                                               w_sink=g('l1_w'), b_sink=g('l1_b'), halo=1)
         dc1_w, dc1_b = ops.conv_wgrad(dz1, y0, packs['p1'], L, 1, w_sink=g('c1_w'), b_sink=g('c1_b'))
-        dy0 = ops.conv_gemm(dz1, packs['p1'], None, transpose=True, lens=L, halo=2)
+        dy0 = ops.conv_gemm(dz1, packs['p1'], None, transpose=True, lens=L, halo=2, out_dtype=h0.dtype)
         dz0, _, dl0_w, dl0_b, _ = ops.ln_bwd(dy0, h0, m0, r0, l0_w, l0_b, None, L, relu_mask=True, seed_post=seeds[0], p_post=p,
                                               w_sink=g('l0_w'), b_sink=g('l0_b'), halo=2)
         dc0_w, dc0_b = ops.conv_wgrad(dz0, x0, packs['p0'], L, 2, w_sink=g('c0_w'), b_sink=g('c0_b'))

@@ -262,7 +262,7 @@ def ln_fwd(a, res, w, b, film, lens, *, seed_pre=0, p_pre=0.0, seed_post=0, p_po
     mean = torch.empty(B, N, dtype=torch.float32, device=a.device)
     rstd = torch.empty(B, N, dtype=torch.float32, device=a.device)
     lib().dx_ln_fwd(_p(a), _p(res), _p(w), _p(b), _p(film), 0 if film is None else film.stride(0), _p(lens), int(halo), _p(y), _p(mean), _p(rstd),
-                    B, N, C, seed_pre, float(p_pre), seed_post, float(p_post), _stream())
+                    B, N, C, seed_pre, float(p_pre), seed_post, float(p_post), _is_bf16(a), _stream())
     return y, mean, rstd
 
 
@@ -277,7 +277,7 @@ def ln_bwd(dy, z, mean, rstd, w, b, film, lens, *, relu_mask=False, want_da=Fals
     dfilm = _zeros(arena, B, 2 * C, device=z.device) if film is not None else None
     lib().dx_ln_bwd(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(film), 0 if film is None else film.stride(0), _p(lens), int(halo),
                     _p(dz), _p(da), _p(dw), _p(db), _p(dfilm), 2 * C, B, N, C, int(relu_mask),
-                    seed_pre, float(p_pre), seed_post, float(p_post), _stream())
+                    seed_pre, float(p_pre), seed_post, float(p_post), _is_bf16(z), _stream())
     return dz, da, (None if w_sink is not None else dw), (None if b_sink is not None else db), dfilm
 
 
