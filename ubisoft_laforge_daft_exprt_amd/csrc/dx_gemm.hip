@@ -309,6 +309,9 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, i
 
   const int tiles_n = (a.N + TOK - 1) / TOK;
   const int total = a.B * tiles_n;
+  __shared__ int limit_s[512];                              // per-utterance skip limits (a scalar global load per tile is ~1 k cycles)
+  for (int i = tid; i < min(a.B, 512); i += 512) limit_s[i] = a.skip_halo >= 0 ? a.lens[i] + a.skip_halo : 0x7fffffff;
+  __syncthreads();
   f32x4 xreg[X_IT];
 #define DX_WS_LOAD(B_, N0_)                                                                                          \
   _Pragma("unroll") for (int it = 0; it < X_IT; ++it) {                                                              \
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, i
     for (; t < total; t += wgs_per_cotile) {
       b = t / tiles_n;
       n0 = (t - b * tiles_n) * TOK;
-      if (!(a.skip_halo >= 0 && n0 >= a.lens[b] + a.skip_halo)) return true;
+      if (n0 < (b < 512 ? limit_s[b] : (a.skip_halo >= 0 ? a.lens[b] + a.skip_halo : 0x7fffffff))) return true;
       if (!a.accumulate) {
         for (int u = tid; u < TOK * 32; u += 512) {
           const int row = u >> 5, q = u & 31;
@@ -732,22 +735,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBf16Args 
     }                                                                                                                         \
   }
 
-  // first live chunk of this split-K slice (interleaved: every slice sees a mix of utterance lengths)
-  int c = blockIdx.z;
-  auto live = [&](int cc, int& b_, int& nc_) {
-    b_ = cc / chunks_per_row;
-    nc_ = (cc - b_ * chunks_per_row) * WB_BK;
-    return !(a.skip_halo >= 0 && nc_ >= a.lens[b_] + a.skip_halo);
+  // chunk walk of this split-K slice (interleaved: every slice sees a mix of utterance lengths).  The per-utterance limits sit in
+  // LDS and (b, chunk-in-row) advance incrementally: a scalar global load + an integer division per chunk cost ~2 k cycles here.
+  __shared__ int limit_s[512];
+  for (int i = tid; i < min(a.B, 512); i += 256) limit_s[i] = a.skip_halo >= 0 ? a.lens[i] + a.skip_halo : 0x7fffffff;
+  __syncthreads();
+  const int step_b = a.ksplit / chunks_per_row, step_k = a.ksplit - step_b * chunks_per_row;
+  int c = blockIdx.z, b = c / chunks_per_row, kc = c - b * chunks_per_row, nc = 0;
+  auto advance = [&]() { c += a.ksplit; b += step_b; kc += step_k; if (kc >= chunks_per_row) { kc -= chunks_per_row; ++b; } };
+  auto live = [&]() {
+    nc = kc * WB_BK;
+    return nc < (b < 512 ? limit_s[b] : (a.skip_halo >= 0 ? a.lens[b] + a.skip_halo : 0x7fffffff));
   };
-  int b = 0, nc = 0;
-  while (c < total && !live(c, b, nc)) c += a.ksplit;
+  while (c < total && !live()) advance();
   if (c < total) DX_WG_LOAD(b, nc);
   while (c < total) {
     __syncthreads();
     DX_WG_STORE();
     __syncthreads();
-    c += a.ksplit;
-    while (c < total && !live(c, b, nc)) c += a.ksplit;
+    advance();
+    while (c < total && !live()) advance();
     if (c < total) DX_WG_LOAD(b, nc);
     if (do_bias) {
 #pragma unroll 8
