@@ -74,12 +74,14 @@ int dx_attention_bwd(const float* qkv, int ld, const float* ctx, const float* dc
  * unmasked prenet LayerNorms whose rows inside the conv halo are still needed */
 int dx_ln_fwd(void* a, const void* res, const float* w, const float* bias, const float* film, int ld_film,
               const int* lens, int halo, void* y, float* mean, float* rstd, int B, int N, int C,
-              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, int io_bf16, void* stream);
+              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, int io_bf16, void* y_bf16_copy, void* stream);
 int dx_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* w, const float* bias,
               const float* film, int ld_film, const int* lens, int halo, void* dz, void* da, float* dw, float* dbias,
               float* dfilm, int ld_dfilm, int B, int N, int C, int relu_mask,
-              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, int io_bf16, void* stream);
-/* io_bf16 = 1 (C = 1024 only): a / res / y and dy / z / dz / da are stored as bf16; statistics and parameter gradients stay fp32 */
+              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, int io_bf16, void* dg_bf16_copy, void* stream);
+/* y_bf16_copy / dg_bf16_copy (optional, C = 128): a second, bf16 copy of y / of the gradient that feeds the GEMM backward.  The
+ * next GEMM would round its fp32 operand to bf16 while staging anyway, so results are bit-identical and the operand costs half the bytes.
+ * io_bf16 = 1 (C = 1024 only): a / res / y and dy / z / dz / da are stored as bf16; statistics and parameter gradients stay fp32 */
 
 /* ---- embeddings, positions, masks, pooling: model.py:119-150, :597-604, :554-557, :687-716 --------------------------- */
 int dx_add_pos(const float* x, const long* sym, const float* emb, const float* pe, const int* lens, float* out,

@@ -280,12 +280,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
 // keeps its whole weight slice [2 chunks][TAPS][128 co][64 ci] (96 KB) in LDS for its lifetime and walks over token tiles
 // (stride = workgroups per channel tile); the next tile's activations are prefetched into registers during the MFMAs.
 // ------------------------------------------------------------------------------------------------
-template <int TAPS>
+template <int TAPS, bool XH>
 __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, int wgs_per_cotile) {
   constexpr int PAD = (TAPS - 1) / 2;
   constexpr int TOK = 128;
   constexpr int XROWS = TOK + TAPS - 1;
-  constexpr int XU = 32;                                   // 16-byte fp32 units per activation row (128 channels)
+  constexpr int XU = XH ? 16 : 32;                         // 16-byte units per activation row (128 channels, bf16 or fp32)
+  constexpr int XE = XH ? 8 : 4;
   constexpr int X_IT = (XROWS * XU + 511) / 512;
   constexpr int W_ROWS = 2 * TAPS * TILE;                  // [chunk][tap][co]
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -317,9 +318,12 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, i
   _Pragma("unroll") for (int it = 0; it < X_IT; ++it) {                                                              \
     const int u = tid + it * 512;                                                                                    \
     const int row = u / XU, q = u % XU;                                                                              \
-    const int n = (N0_) + row - PAD, ci = q * 4;                                                                     \
+    const int n = (N0_) + row - PAD, ci = q * XE;                                                                    \
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                                             \
-    if (u < XROWS * XU && n >= 0 && n < a.N && ci < a.Cin) v = *reinterpret_cast<const f32x4*>(a.X + ((size_t)(B_) * a.N + n) * a.ldx + ci); \
+    if (u < XROWS * XU && n >= 0 && n < a.N && ci < a.Cin) {                                                         \
+      if constexpr (XH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.X) + ((size_t)(B_) * a.N + n) * a.ldx + ci); \
+      else v = *reinterpret_cast<const f32x4*>(a.X + ((size_t)(B_) * a.N + n) * a.ldx + ci);                         \
+    }                                                                                                                \
     xreg[it] = v;                                                                                                    \
   }
   // next live tile of this workgroup (padding tiles beyond the halo are zero-filled on the way)
@@ -355,9 +359,11 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, i
 #pragma unroll
     for (int it = 0; it < X_IT; ++it) {
       const int u = tid + it * 512;
-      const int row = u / XU, q = u % XU;                  // q: float4 index 0..31 -> chunk q>>4, 8-byte slot (q&15)
-      if (u < XROWS * XU)
-        *reinterpret_cast<uint2*>(Xs + (q >> 4) * (XROWS * 128) + lds_off(row, (q & 15) >> 1) + ((q & 1) << 3)) = pack_bf16x4v(xreg[it]);
+      const int row = u / XU, q = u % XU;                  // fp32: q = float4 index 0..31 -> chunk q>>4, 8-byte slot (q&15); bf16: q = 16-byte unit
+      if (u < XROWS * XU) {
+        if constexpr (XH) *reinterpret_cast<f32x4*>(Xs + (q >> 3) * (XROWS * 128) + lds_off(row, q & 7)) = xreg[it];
+        else *reinterpret_cast<uint2*>(Xs + (q >> 4) * (XROWS * 128) + lds_off(row, (q & 15) >> 1) + ((q & 1) << 3)) = pack_bf16x4v(xreg[it]);
+      }
     }
     __syncthreads();
     t += wgs_per_cotile;
@@ -510,19 +516,19 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, i
 #undef DX_WS_LOAD
 }
 
-template <int TAPS>
+template <int TAPS, bool XH>
 void launch_conv_ws(const ConvGemmArgs& a, hipStream_t s) {
   const size_t smem = (size_t)(2 * TAPS * TILE) * 128 + std::max<size_t>((size_t)2 * (128 + TAPS - 1) * 128, (size_t)128 * 288);
   static bool configured = false;
   if (!configured) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<TAPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<TAPS, XH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     configured = true;
   }
   const int co_tiles = a.CoutP / TILE;
   const int total = a.B * dx_cdiv(a.N, 128);
   const int per_cu = smem * 2 <= 160 * 1024 ? 2 : 1;       // TAPS=1 fits twice per CU
   const int wgs = std::max(1, std::min(total, (256 * per_cu) / co_tiles));
-  hipLaunchKernelGGL((conv_ws_kernel<TAPS>), dim3(wgs, co_tiles), dim3(512), smem, s, a, wgs);
+  hipLaunchKernelGGL((conv_ws_kernel<TAPS, XH>), dim3(wgs, co_tiles), dim3(512), smem, s, a, wgs);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -980,8 +986,9 @@ int dx_conv_gemm(const void* Xv, int ldx, const void* Wp, const float* bias, voi
   hipStream_t s = (hipStream_t)stream;
   dx_prof_begin(DX_PROF_CONV_GEMM, s);
   static const int use_ws = getenv("DX_CONV_WS") ? atoi(getenv("DX_CONV_WS")) : 1;
-  if (bf16 && use_ws && d[1] == 128 && !x_bf16 && (long)B * dx_cdiv(N, 128) >= 64) {      // short-K layers: weight-stationary persistent kernel
-    if (taps == 3) launch_conv_ws<3>(a, s); else launch_conv_ws<1>(a, s);
+  if (bf16 && use_ws && d[1] == 128 && (long)B * dx_cdiv(N, 128) >= 64) {      // short-K layers: weight-stationary persistent kernel
+    if (x_bf16) { if (taps == 3) launch_conv_ws<3, true>(a, s); else launch_conv_ws<1, true>(a, s); }
+    else { if (taps == 3) launch_conv_ws<3, false>(a, s); else launch_conv_ws<1, false>(a, s); }
   } else if (bf16) { if (taps == 3) launch_conv<__bf16, 3>(a, s); else launch_conv<__bf16, 1>(a, s); }
   else      { if (taps == 3) launch_conv<float, 3>(a, s);  else launch_conv<float, 1>(a, s); }
   dx_prof_end(DX_PROF_CONV_GEMM, s);

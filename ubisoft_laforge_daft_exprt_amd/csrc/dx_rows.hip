@@ -23,6 +23,7 @@ struct LnArgs {
   const int* lens;     // [B] or null (no mask)
   int halo;            // rows n >= lens[b] + halo are padding nobody reads: zero-filled, not computed (halo 0 = the reference's mask)
   float* y;            // [rows][C]
+  __bf16* y_h;         // optional bf16 copy of y (GEMM operand of the next layer: same rounding as its staging would apply)
   float* mean; float* rstd;            // [rows]
   int B, N;
   uint64_t seed_pre; uint32_t thresh_pre; float inv_keep_pre;     // dropout on `a` (thresh 0 = off)
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
 #pragma unroll
       for (int e = 0; e < E; ++e) z[e] = 0.f;
       row_store<C>(Y + row * C, lane, z);
+      if constexpr (sizeof(IO) == 4 && C < 256) { if (a.y_h) *reinterpret_cast<unsigned*>(a.y_h + row * C + lane * 2) = 0u; }
       if (a.thresh_pre || a.res) row_store<C>(A + row * C, lane, z);
       if (lane == 0) { a.mean[row] = 0.f; a.rstd[row] = 0.f; }
       continue;
@@ -138,6 +140,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
       y[e] = valid ? t : 0.f;
     }
     row_store<C>(Y + row * C, lane, y);
+    if constexpr (sizeof(IO) == 4 && C < 256) {
+      if (a.y_h) {
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        bf16x2_t h2; h2[0] = (__bf16)y[0]; h2[1] = (__bf16)y[1];
+        *reinterpret_cast<bf16x2_t*>(a.y_h + row * C + lane * 2) = h2;
+      }
+    }
   }
 }
 
@@ -149,6 +158,7 @@ struct LnBwdArgs {
   const int* lens; int halo;
   float* dz;           // [rows][C] gradient w.r.t. z (== residual branch gradient)
   float* da;           // [rows][C] gradient w.r.t. the pre-dropout GEMM output, or null (then dz serves)
+  __bf16* dg_h;        // optional bf16 copy of the gradient that feeds the GEMM backward (da if present, else dz)
   float* dw; float* dbias;             // [C] accumulated (atomics)
   float* dfilm; int ld_dfilm;          // [B][>=2C] accumulated, or null
   int B, N, rows_per_block;
@@ -189,6 +199,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
       for (int e = 0; e < E; ++e) dzv[e] = 0.f;
       row_store<C>(DZ + row * C, lane, dzv);
       if (a.da) row_store<C>(DA + row * C, lane, dzv);
+      if constexpr (sizeof(IO) == 4 && C < 256) { if (a.dg_h) *reinterpret_cast<unsigned*>(a.dg_h + row * C + lane * 2) = 0u; }
       continue;
     }
     float dy[E], z[E];
@@ -218,12 +229,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
       if (a.relu_mask && !(z[e] > 0.f)) dzv[e] = 0.f;
     }
     row_store<C>(DZ + row * C, lane, dzv);
-    if (a.da) {
-      if (a.thresh_pre) {
+    if ((a.da || a.dg_h) && a.thresh_pre) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) dzv[e] *= dx_dropout_scale(a.seed_pre, (uint64_t)row * C + row_col<C>(lane, e), a.thresh_pre, a.inv_keep_pre);
+      for (int e = 0; e < E; ++e) dzv[e] *= dx_dropout_scale(a.seed_pre, (uint64_t)row * C + row_col<C>(lane, e), a.thresh_pre, a.inv_keep_pre);
+    }
+    if (a.da) row_store<C>(DA + row * C, lane, dzv);
+    if constexpr (sizeof(IO) == 4 && C < 256) {
+      if (a.dg_h) {
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        bf16x2_t h2; h2[0] = (__bf16)dzv[0]; h2[1] = (__bf16)dzv[1];
+        *reinterpret_cast<bf16x2_t*>(a.dg_h + row * C + lane * 2) = h2;
       }
-      row_store<C>(DA + row * C, lane, dzv);
     }
   }
   // block reduction of the per-channel sums, then one atomic per channel per block
@@ -517,15 +533,16 @@ extern "C" {
 
 int dx_ln_fwd(void* av, const void* resv, const float* w, const float* bias, const float* film, int ld_film,
               const int* lens, int halo, void* yv, float* mean, float* rstd, int B, int N, int C,
-              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, int io_bf16, void* stream) {
+              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, int io_bf16, void* y_bf16_copy, void* stream) {
   float* a = (float*)av; const float* res = (const float*)resv; float* y = (float*)yv;
+  DX_REQUIRE(!y_bf16_copy || (C == 128 && !io_bf16), "dx_ln_fwd: the bf16 shadow output is for fp32 rows with C = 128");
   DX_REQUIRE(a && w && bias && y && mean && rstd, "dx_ln_fwd: null pointer");
   DX_REQUIRE(!io_bf16 || C == 1024, "dx_ln_fwd: bf16 rows are supported for C = 1024 only");
   DX_REQUIRE(C == 128 || C == 1024, "dx_ln_fwd: C must be 128 or 1024 (got %d)", C);
   DX_REQUIRE(B > 0 && N > 0, "dx_ln_fwd: bad dims");
   DX_REQUIRE(p_pre >= 0.f && p_pre < 1.f && p_post >= 0.f && p_post < 1.f, "dx_ln_fwd: dropout p out of range");
   DX_REQUIRE(!film || ld_film >= 2 * C, "dx_ln_fwd: ld_film too small");
-  LnArgs k{a, res, w, bias, film, ld_film, lens, halo, y, mean, rstd, B, N,
+  LnArgs k{a, res, w, bias, film, ld_film, lens, halo, y, (__bf16*)y_bf16_copy, mean, rstd, B, N,
            seed_pre, (uint32_t)lrintf(p_pre * 65536.f), 1.f / (1.f - p_pre),
            seed_post, (uint32_t)lrintf(p_post * 65536.f), 1.f / (1.f - p_post)};
   hipStream_t s = (hipStream_t)stream;
@@ -542,14 +559,15 @@ int dx_ln_fwd(void* av, const void* resv, const float* w, const float* bias, con
 int dx_ln_bwd(const void* dyv, const void* zv, const float* mean, const float* rstd, const float* w, const float* bias,
               const float* film, int ld_film, const int* lens, int halo, void* dzv, void* dav, float* dw, float* dbias,
               float* dfilm, int ld_dfilm, int B, int N, int C, int relu_mask,
-              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, int io_bf16, void* stream) {
-  const float* dy = (const float*)dyv; const float* z = (const float*)zv; float* dz = (float*)dzv; float* da = (float*)dav;
+              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, int io_bf16, void* dg_bf16_copy, void* stream) {
+  const float* dy = (const float*)dyv;
+  DX_REQUIRE(!dg_bf16_copy || (C == 128 && !io_bf16), "dx_ln_bwd: the bf16 shadow output is for fp32 rows with C = 128"); const float* z = (const float*)zv; float* dz = (float*)dzv; float* da = (float*)dav;
   DX_REQUIRE(!io_bf16 || C == 1024, "dx_ln_bwd: bf16 rows are supported for C = 1024 only");
   DX_REQUIRE(dy && z && mean && rstd && w && bias && dz && dw && dbias, "dx_ln_bwd: null pointer");
   DX_REQUIRE(C == 128 || C == 1024, "dx_ln_bwd: C must be 128 or 1024 (got %d)", C);
   DX_REQUIRE((film == nullptr) == (dfilm == nullptr), "dx_ln_bwd: film and dfilm must come together");
   const int rpb = 64;
-  LnBwdArgs k{dy, z, mean, rstd, w, bias, film, ld_film, lens, halo, dz, da, dw, dbias, dfilm, ld_dfilm, B, N, rpb, relu_mask,
+  LnBwdArgs k{dy, z, mean, rstd, w, bias, film, ld_film, lens, halo, dz, da, (__bf16*)dg_bf16_copy, dw, dbias, dfilm, ld_dfilm, B, N, rpb, relu_mask,
               seed_pre, (uint32_t)lrintf(p_pre * 65536.f), 1.f / (1.f - p_pre),
               seed_post, (uint32_t)lrintf(p_post * 65536.f), 1.f / (1.f - p_post)};
   hipStream_t s = (hipStream_t)stream;

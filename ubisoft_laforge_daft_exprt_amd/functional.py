@@ -149,11 +149,14 @@ class FFTBlockFn(torch.autograd.Function):
         qkv = ops.conv_gemm(x, packs['in'], in_b, lens=L, halo=0)
         att, lse = ops.attention_fwd(qkv, lens.i32, heads, s_attn, p_attn)
         z1 = ops.conv_gemm(att, packs['out'], out_b, lens=L, halo=0)
-        y1, mean1, rstd1 = ops.ln_fwd(z1, x, ln1_w, ln1_b, None, lens.i32, seed_pre=s_ln1, p_pre=p_attn)
-        h = ops.conv_gemm(y1, packs['c1'], c1_b, relu=True, lens=L, halo=1, out_dtype=ops.hidden_dtype())   # conv2 reads one row past the end
+        sh = ops.gemm_shadow()                     # bf16 mode: GEMM operands also exist as bf16 copies written by their producers
+        ln1 = ops.ln_fwd(z1, x, ln1_w, ln1_b, None, lens.i32, seed_pre=s_ln1, p_pre=p_attn, shadow=sh)
+        y1, mean1, rstd1 = ln1[:3]
+        y1g = ln1[3] if sh else y1                 # the copy the GEMMs read
+        h = ops.conv_gemm(y1g, packs['c1'], c1_b, relu=True, lens=L, halo=1, out_dtype=ops.hidden_dtype())   # conv2 reads one row past the end
         z2 = ops.conv_gemm(h, packs['c2'], c2_b, lens=L, halo=0)
         y2, mean2, rstd2 = ops.ln_fwd(z2, y1, ln2_w, ln2_b, film, lens.i32, seed_pre=s_ln2, p_pre=p_conv)
-        ctx.save_for_backward(x, film, qkv, att, lse, z1, mean1, rstd1, y1, h, z2, mean2, rstd2, ln1_w, ln1_b, ln2_w, ln2_b)
+        ctx.save_for_backward(x, film, qkv, att, lse, z1, mean1, rstd1, y1g, h, z2, mean2, rstd2, ln1_w, ln1_b, ln2_w, ln2_b)
         ctx.lens, ctx.packs, ctx.heads = lens, packs, heads
         ctx.drop = (p_attn, p_conv, s_attn, s_ln1, s_ln2)
         return y2
@@ -172,16 +175,19 @@ class FFTBlockFn(torch.autograd.Function):
         P = packs.get('params', {})
         sk = {k: _sink(v) for k, v in P.items()}
         g = sk.get
-        dz2, da2, dln2_w, dln2_b, dfilm = ops.ln_bwd(dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, L, want_da=p_conv > 0, seed_pre=s_ln2,
-                                                      p_pre=p_conv, arena=arena, w_sink=g('ln2_w'), b_sink=g('ln2_b'))
-        dff = da2 if da2 is not None else dz2
+        sh = ops.gemm_shadow()
+        r2 = ops.ln_bwd(dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, L, want_da=p_conv > 0, seed_pre=s_ln2,
+                        p_pre=p_conv, arena=arena, w_sink=g('ln2_w'), b_sink=g('ln2_b'), shadow=sh)
+        dz2, da2, dln2_w, dln2_b, dfilm = r2[:5]
+        dff = r2[5] if sh else (da2 if da2 is not None else dz2)      # gradient w.r.t. the conv2 output, as the GEMMs read it
         dc2_w, dc2_b = ops.conv_wgrad(dff, h, packs['c2'], L, 0, arena=arena, w_sink=g('c2_w'), b_sink=g('c2_b'))
         dh = ops.conv_gemm(dff, packs['c2'], None, transpose=True, relu_aux=h, lens=L, halo=1, out_dtype=h.dtype)
         dc1_w, dc1_b = ops.conv_wgrad(dh, y1, packs['c1'], L, 1, arena=arena, w_sink=g('c1_w'), b_sink=g('c1_b'))
         dy1 = ops.conv_gemm(dh, packs['c1'], None, transpose=True, out=dz2, accumulate=True, lens=L, halo=0)  # + residual branch
-        dz1, da1, dln1_w, dln1_b, _ = ops.ln_bwd(dy1, z1, mean1, rstd1, ln1_w, ln1_b, None, L, want_da=p_attn > 0, seed_pre=s_ln1,
-                                                  p_pre=p_attn, arena=arena, w_sink=g('ln1_w'), b_sink=g('ln1_b'))
-        dproj = da1 if da1 is not None else dz1
+        r1 = ops.ln_bwd(dy1, z1, mean1, rstd1, ln1_w, ln1_b, None, L, want_da=p_attn > 0, seed_pre=s_ln1,
+                        p_pre=p_attn, arena=arena, w_sink=g('ln1_w'), b_sink=g('ln1_b'), shadow=sh)
+        dz1, da1, dln1_w, dln1_b = r1[:4]
+        dproj = r1[5] if sh else (da1 if da1 is not None else dz1)
         dout_w, dout_b = ops.conv_wgrad(dproj, att, packs['out'], L, 0, arena=arena, w_sink=g('out_w'), b_sink=g('out_b'))
         datt = ops.conv_gemm(dproj, packs['out'], None, transpose=True, lens=L, halo=0)
         dqkv = ops.attention_bwd(qkv, att, datt, lse, L, ctx.heads, s_attn, p_attn)

@@ -255,30 +255,38 @@ def attention_bwd(qkv, ctx, dctx, lse, lens, heads, seed, p_drop):
     return dqkv
 
 
-def ln_fwd(a, res, w, b, film, lens, *, seed_pre=0, p_pre=0.0, seed_post=0, p_post=0.0, halo=0):
-    """In place on ``a`` (becomes z = drop(a) + res).  Returns (y, mean, rstd)."""
+def gemm_shadow():
+    """True when producers should also emit a bf16 copy of a 128-wide fp32 tensor that the next GEMM consumes (bf16 operand mode)."""
+    return bool(_PRECISION['bf16'])
+
+
+def ln_fwd(a, res, w, b, film, lens, *, seed_pre=0, p_pre=0.0, seed_post=0, p_post=0.0, halo=0, shadow=False):
+    """In place on ``a`` (becomes z = drop(a) + res).  Returns (y, mean, rstd) or, with ``shadow``, (y, mean, rstd, y_bf16)."""
     B, N, C = a.shape
     y = torch.empty_like(a)
+    y_h = torch.empty(B, N, C, dtype=torch.bfloat16, device=a.device) if shadow else None
     mean = torch.empty(B, N, dtype=torch.float32, device=a.device)
     rstd = torch.empty(B, N, dtype=torch.float32, device=a.device)
     lib().dx_ln_fwd(_p(a), _p(res), _p(w), _p(b), _p(film), 0 if film is None else film.stride(0), _p(lens), int(halo), _p(y), _p(mean), _p(rstd),
-                    B, N, C, seed_pre, float(p_pre), seed_post, float(p_post), _is_bf16(a), _stream())
-    return y, mean, rstd
+                    B, N, C, seed_pre, float(p_pre), seed_post, float(p_post), _is_bf16(a), _p(y_h), _stream())
+    return (y, mean, rstd, y_h) if shadow else (y, mean, rstd)
 
 
 def ln_bwd(dy, z, mean, rstd, w, b, film, lens, *, relu_mask=False, want_da=False, seed_pre=0, p_pre=0.0, seed_post=0, p_post=0.0,
-           arena=None, w_sink=None, b_sink=None, halo=0):
-    """Returns (dz, da or None, dw, db, dfilm or None); dw/db are None when accumulated straight into the given sinks."""
+           arena=None, w_sink=None, b_sink=None, halo=0, shadow=False):
+    """Returns (dz, da or None, dw, db, dfilm or None[, dg_bf16]); dw/db are None when accumulated straight into the given sinks."""
     B, N, C = z.shape
     dz = torch.empty_like(z)
-    da = torch.empty_like(z) if want_da else None
+    dg_h = torch.empty(B, N, C, dtype=torch.bfloat16, device=z.device) if shadow else None
+    da = torch.empty_like(z) if (want_da and not shadow) else None      # with a bf16 shadow the GEMMs read that copy instead
     dw = w_sink if w_sink is not None else _zeros(arena, C, device=z.device)
     db = b_sink if b_sink is not None else _zeros(arena, C, device=z.device)
     dfilm = _zeros(arena, B, 2 * C, device=z.device) if film is not None else None
     lib().dx_ln_bwd(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(film), 0 if film is None else film.stride(0), _p(lens), int(halo),
                     _p(dz), _p(da), _p(dw), _p(db), _p(dfilm), 2 * C, B, N, C, int(relu_mask),
-                    seed_pre, float(p_pre), seed_post, float(p_post), _is_bf16(z), _stream())
-    return dz, da, (None if w_sink is not None else dw), (None if b_sink is not None else db), dfilm
+                    seed_pre, float(p_pre), seed_post, float(p_post), _is_bf16(z), _p(dg_h), _stream())
+    out = (dz, da, (None if w_sink is not None else dw), (None if b_sink is not None else db), dfilm)
+    return out + (dg_h,) if shadow else out
 
 
 def add_pos(x, sym, emb, pe, lens):
