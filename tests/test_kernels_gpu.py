@@ -203,6 +203,12 @@ def _attention_forward_backward(ops, B, N, lens, tol_f, tol_b):
     dqkv = ops.attention_bwd(qkv.detach(), ctx, dctx, lse, ln, heads, 0, 0.0)
     assert rel_err(dqkv, qkv.grad) < tol_b
     assert torch.isfinite(dqkv).all()
+    if ops.get_precision() == 'bf16':                      # bf16-stored q/k/v and dqkv (what the FFT block uses in bf16 mode)
+        qh = qkv.detach().to(torch.bfloat16)
+        ctx_h, lse_h = ops.attention_fwd(qh, ln, heads, 0, 0.0)
+        assert rel_err(ctx_h, ref.detach()) < tol_f
+        dq_h = ops.attention_bwd(qh, ctx_h, dctx, lse_h, ln, heads, 0, 0.0, out_dtype=torch.bfloat16)
+        assert dq_h.dtype == torch.bfloat16 and rel_err(dq_h.float(), qkv.grad) < tol_b
 
 
 @pytest.mark.parametrize('precision', ['f32', 'bf16'])

@@ -391,21 +391,38 @@ __device__ __forceinline__ void stage_tile_bf16(unsigned char* dst, const float*
 
 // software pipeline: the NEXT tile's rows are fetched into registers (4 x 16 bytes per thread per tensor) before the current
 // tile's MFMA/softmax work, and converted + written to LDS after it
-#define DX_TILE_LOAD(REG, BASE, LD, COL0, R0, NROWS)                                                              \
-  _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                                             \
-    const int u_ = tid + it * 256;                                                                                \
-    const int row_ = u_ >> 4, q_ = u_ & 15;                                                                       \
-    f32x4 v_ = f32x4{0.f, 0.f, 0.f, 0.f};                                                                         \
-    if ((R0) + row_ < (NROWS)) v_ = *reinterpret_cast<const f32x4*>((BASE) + (size_t)((R0) + row_) * (LD) + (COL0) + q_ * 4); \
-    REG[it] = v_;                                                                                                 \
+#define DX_TILE_LOAD(QT_, REG, BASE, LD, COL0, R0, NROWS)                                                         \
+  if constexpr (sizeof(QT_) == 4) {                                                                               \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                                           \
+      const int u_ = tid + it * 256;                                                                              \
+      const int row_ = u_ >> 4, q_ = u_ & 15;                                                                     \
+      f32x4 v_ = f32x4{0.f, 0.f, 0.f, 0.f};                                                                       \
+      if ((R0) + row_ < (NROWS)) v_ = *reinterpret_cast<const f32x4*>((BASE) + (size_t)((R0) + row_) * (LD) + (COL0) + q_ * 4); \
+      REG[it] = v_;                                                                                               \
+    }                                                                                                             \
+  } else {                                                                                                        \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                                           \
+      const int u_ = tid + it * 256;                                                                              \
+      const int row_ = u_ >> 3, q_ = u_ & 7;                                                                      \
+      f32x4 v_ = f32x4{0.f, 0.f, 0.f, 0.f};                                                                       \
+      if ((R0) + row_ < (NROWS)) v_ = *reinterpret_cast<const f32x4*>((BASE) + (size_t)((R0) + row_) * (LD) + (COL0) + q_ * 8); \
+      REG[it] = v_;                                                                                               \
+    }                                                                                                             \
   }
-#define DX_TILE_STORE(REG, DST)                                                                                   \
-  _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                                             \
-    const int u_ = tid + it * 256;                                                                                \
-    const int row_ = u_ >> 4, q_ = u_ & 15;                                                                       \
-    bf16x4 h_;                                                                                                    \
-    h_[0] = (__bf16)REG[it][0]; h_[1] = (__bf16)REG[it][1]; h_[2] = (__bf16)REG[it][2]; h_[3] = (__bf16)REG[it][3]; \
-    *reinterpret_cast<uint2*>((DST) + sw_off(row_, q_ >> 1) + ((q_ & 1) << 3)) = __builtin_bit_cast(uint2, h_);  \
+#define DX_TILE_STORE(QT_, REG, DST)                                                                              \
+  if constexpr (sizeof(QT_) == 4) {                                                                               \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                                           \
+      const int u_ = tid + it * 256;                                                                              \
+      const int row_ = u_ >> 4, q_ = u_ & 15;                                                                     \
+      bf16x4 h_;                                                                                                  \
+      h_[0] = (__bf16)REG[it][0]; h_[1] = (__bf16)REG[it][1]; h_[2] = (__bf16)REG[it][2]; h_[3] = (__bf16)REG[it][3]; \
+      *reinterpret_cast<uint2*>((DST) + sw_off(row_, q_ >> 1) + ((q_ & 1) << 3)) = __builtin_bit_cast(uint2, h_); \
+    }                                                                                                             \
+  } else {                                                                                                        \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                                           \
+      const int u_ = tid + it * 256;                                                                              \
+      *reinterpret_cast<f32x4*>((DST) + sw_off(u_ >> 3, u_ & 7)) = REG[it];                                       \
+    }                                                                                                             \
   }
 
 // row fragment: 8 consecutive columns (32*ks + 8*g ..) of row `row`
@@ -439,8 +456,22 @@ __device__ __forceinline__ bf16x8 load_row8(const float* p, float scale) {
   h[4] = (__bf16)(b.x * scale); h[5] = (__bf16)(b.y * scale); h[6] = (__bf16)(b.z * scale); h[7] = (__bf16)(b.w * scale);
   return h;
 }
+__device__ __forceinline__ bf16x8 load_row8(const __bf16* p, float scale) {
+  bf16x8 h = *reinterpret_cast<const bf16x8*>(p);
+  if (scale != 1.f) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (__bf16)((float)h[e] * scale);   // scale is a power of two: exact
+  }
+  return h;
+}
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
+__device__ __forceinline__ void store4(__bf16* p, float a, float b, float c, float d) {
+  bf16x4 h; h[0] = (__bf16)a; h[1] = (__bf16)b; h[2] = (__bf16)c; h[3] = (__bf16)d;
+  *reinterpret_cast<bf16x4*>(p) = h;
+}
 #define DX_MFMA_BF16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A), (B), (C), 0, 0, 0)
 
+template <typename QT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * 128];
@@ -448,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int len = a.lens[b];
-  const float* base = a.qkv + (size_t)b * a.N * a.ld;
+  const QT* base = reinterpret_cast<const QT*>(a.qkv) + (size_t)b * a.N * a.ld;
   const int qrow = q0 + wave * 16 + r;
   float* out = a.ctx + ((size_t)b * a.N + qrow) * a.ldc + h * HD;
   if (q0 >= len) {
@@ -470,17 +501,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a)
   const int bh = b * a.H + h;
   const int ntiles = (len + 63) / 64;
   f32x4 kreg[4], vreg[4];
-  DX_TILE_LOAD(kreg, base, a.ld, a.D + h * HD, 0, a.N)
-  DX_TILE_LOAD(vreg, base, a.ld, 2 * a.D + h * HD, 0, a.N)
+  DX_TILE_LOAD(QT, kreg, base, a.ld, a.D + h * HD, 0, a.N)
+  DX_TILE_LOAD(QT, vreg, base, a.ld, 2 * a.D + h * HD, 0, a.N)
   for (int kt0 = 0; kt0 < ntiles; ++kt0) {
     const int kbase = kt0 * 64;
     __syncthreads();
-    DX_TILE_STORE(kreg, Ks)
-    DX_TILE_STORE(vreg, Vs)
+    DX_TILE_STORE(QT, kreg, Ks)
+    DX_TILE_STORE(QT, vreg, Vs)
     __syncthreads();
     if (kt0 + 1 < ntiles) {
-      DX_TILE_LOAD(kreg, base, a.ld, a.D + h * HD, kbase + 64, a.N)
-      DX_TILE_LOAD(vreg, base, a.ld, 2 * a.D + h * HD, kbase + 64, a.N)
+      DX_TILE_LOAD(QT, kreg, base, a.ld, a.D + h * HD, kbase + 64, a.N)
+      DX_TILE_LOAD(QT, vreg, base, a.ld, 2 * a.D + h * HD, kbase + 64, a.N)
     }
     f32x4 st[4];
     float mx = -INFINITY;
@@ -537,6 +568,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a)
   }
 }
 
+template <typename QT, typename OT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * 128];
@@ -544,13 +576,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int len = a.lens[b];
-  const float* base = a.qkv + (size_t)b * a.N * a.ld;
+  const QT* base = reinterpret_cast<const QT*>(a.qkv) + (size_t)b * a.N * a.ld;
   const int qrow = q0 + wave * 16 + r;
-  float* out = a.dqkv + ((size_t)b * a.N + qrow) * a.ldg + h * HD;
+  OT* out = reinterpret_cast<OT*>(a.dqkv) + ((size_t)b * a.N + qrow) * a.ldg + h * HD;
   if (q0 >= len) {
     if (qrow < a.N) {
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<float4*>(out + dt * 16 + g * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int dt = 0; dt < 4; ++dt) store4(out + dt * 16 + g * 4, 0.f, 0.f, 0.f, 0.f);
     }
     return;
   }
@@ -569,17 +601,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
   for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ntiles = (len + 63) / 64;
   f32x4 kreg[4], vreg[4];
-  DX_TILE_LOAD(kreg, base, a.ld, a.D + h * HD, 0, a.N)
-  DX_TILE_LOAD(vreg, base, a.ld, 2 * a.D + h * HD, 0, a.N)
+  DX_TILE_LOAD(QT, kreg, base, a.ld, a.D + h * HD, 0, a.N)
+  DX_TILE_LOAD(QT, vreg, base, a.ld, 2 * a.D + h * HD, 0, a.N)
   for (int kt0 = 0; kt0 < ntiles; ++kt0) {
     const int kbase = kt0 * 64;
     __syncthreads();
-    DX_TILE_STORE(kreg, Ks)
-    DX_TILE_STORE(vreg, Vs)
+    DX_TILE_STORE(QT, kreg, Ks)
+    DX_TILE_STORE(QT, vreg, Vs)
     __syncthreads();
     if (kt0 + 1 < ntiles) {
-      DX_TILE_LOAD(kreg, base, a.ld, a.D + h * HD, kbase + 64, a.N)
-      DX_TILE_LOAD(vreg, base, a.ld, 2 * a.D + h * HD, kbase + 64, a.N)
+      DX_TILE_LOAD(QT, kreg, base, a.ld, a.D + h * HD, kbase + 64, a.N)
+      DX_TILE_LOAD(QT, vreg, base, a.ld, 2 * a.D + h * HD, kbase + 64, a.N)
     }
     f32x4 ds[4];
 #pragma unroll
@@ -613,10 +645,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
     const float z = qrow < len ? 1.f : 0.f;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
-      *reinterpret_cast<float4*>(out + dt * 16 + g * 4) = make_float4(dq[dt][0] * z, dq[dt][1] * z, dq[dt][2] * z, dq[dt][3] * z);
+      store4(out + dt * 16 + g * 4, dq[dt][0] * z, dq[dt][1] * z, dq[dt][2] * z, dq[dt][3] * z);
   }
 }
 
+template <typename QT, typename OT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwdArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char Qs[64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char Gs[64 * 128];
@@ -625,17 +658,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwd
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int len = a.lens[b];
-  const float* base = a.qkv + (size_t)b * a.N * a.ld;
+  const QT* base = reinterpret_cast<const QT*>(a.qkv) + (size_t)b * a.N * a.ld;
   const float* gbase = a.dctx + (size_t)b * a.N * a.ldc;
   const int krow = k0 + wave * 16 + r;
-  float* outk = a.dqkv + ((size_t)b * a.N + krow) * a.ldg + a.D + h * HD;
-  float* outv = a.dqkv + ((size_t)b * a.N + krow) * a.ldg + 2 * a.D + h * HD;
+  OT* outk = reinterpret_cast<OT*>(a.dqkv) + ((size_t)b * a.N + krow) * a.ldg + a.D + h * HD;
+  OT* outv = reinterpret_cast<OT*>(a.dqkv) + ((size_t)b * a.N + krow) * a.ldg + 2 * a.D + h * HD;
   if (k0 >= len) {
     if (krow < a.N) {
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        *reinterpret_cast<float4*>(outk + dt * 16 + g * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(outv + dt * 16 + g * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        store4(outk + dt * 16 + g * 4, 0.f, 0.f, 0.f, 0.f);
+        store4(outv + dt * 16 + g * 4, 0.f, 0.f, 0.f, 0.f);
       }
     }
     return;
@@ -655,19 +688,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwd
   const int ntiles = (len + 63) / 64;
   f32x4 qreg[4], greg[4];
   float lse_r = 0.f, delta_r = 0.f;
-  DX_TILE_LOAD(qreg, base, a.ld, h * HD, 0, a.N)
-  DX_TILE_LOAD(greg, gbase, a.ldc, h * HD, 0, a.N)
+  DX_TILE_LOAD(QT, qreg, base, a.ld, h * HD, 0, a.N)
+  DX_TILE_LOAD(float, greg, gbase, a.ldc, h * HD, 0, a.N)
   if (tid < 64 && tid < a.N) { lse_r = a.lse[(size_t)bh * a.N + tid]; delta_r = a.delta[(size_t)bh * a.N + tid]; }
   for (int qt0 = 0; qt0 < ntiles; ++qt0) {
     const int qbase = qt0 * 64;
     __syncthreads();
-    DX_TILE_STORE(qreg, Qs)
-    DX_TILE_STORE(greg, Gs)
+    DX_TILE_STORE(QT, qreg, Qs)
+    DX_TILE_STORE(float, greg, Gs)
     if (tid < 64) { lse_s[tid] = lse_r; delta_s[tid] = delta_r; }
     __syncthreads();
     if (qt0 + 1 < ntiles) {
-      DX_TILE_LOAD(qreg, base, a.ld, h * HD, qbase + 64, a.N)
-      DX_TILE_LOAD(greg, gbase, a.ldc, h * HD, qbase + 64, a.N)
+      DX_TILE_LOAD(QT, qreg, base, a.ld, h * HD, qbase + 64, a.N)
+      DX_TILE_LOAD(float, greg, gbase, a.ldc, h * HD, qbase + 64, a.N)
       const int qn = qbase + 64 + tid;
       lse_r = (tid < 64 && qn < a.N) ? a.lse[(size_t)bh * a.N + qn] : 0.f;
       delta_r = (tid < 64 && qn < a.N) ? a.delta[(size_t)bh * a.N + qn] : 0.f;
@@ -707,8 +740,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwd
   if (krow < a.N) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      *reinterpret_cast<float4*>(outk + dt * 16 + g * 4) = make_float4(dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]);
-      *reinterpret_cast<float4*>(outv + dt * 16 + g * 4) = make_float4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
+      store4(outk + dt * 16 + g * 4, dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]);
+      store4(outv + dt * 16 + g * 4, dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
     }
   }
 }
@@ -728,15 +761,18 @@ int check_common(const char* who, const void* qkv, int ld, int B, int N, int H, 
 
 extern "C" {
 
-int dx_attention_fwd(const float* qkv, int ld, const int* lens, float* ctx, int ldc, float* lse,
-                     int B, int N, int H, int D, uint64_t seed, float p_drop, int bf16, void* stream) {
+int dx_attention_fwd(const void* qkvv, int ld, const int* lens, float* ctx, int ldc, float* lse,
+                     int B, int N, int H, int D, uint64_t seed, float p_drop, int bf16, int qkv_bf16, void* stream) {
+  const float* qkv = (const float*)qkvv;
   if (int rc = check_common("dx_attention_fwd", qkv, ld, B, N, H, D)) return rc;
+  DX_REQUIRE(!qkv_bf16 || (bf16 && (ld % 8) == 0), "dx_attention_fwd: bf16-stored qkv needs bf16 mode and ld %% 8 == 0");
   DX_REQUIRE(lens && ctx && lse && ldc >= D && (ldc % 4) == 0 && ((uintptr_t)ctx % 16) == 0, "dx_attention_fwd: bad output arguments");
   DX_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "dx_attention_fwd: dropout p out of range");
   AttnArgs a{qkv, ld, lens, ctx, ldc, lse, B, N, H, D, seed, (uint32_t)lrintf(p_drop * 65536.f), 1.f / (1.f - p_drop)};
   hipStream_t s = (hipStream_t)stream;
   dx_prof_begin(DX_PROF_ATTN_FWD, s);
-  if (bf16) hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
+  if (bf16 && qkv_bf16) hipLaunchKernelGGL(attn_fwd_bf16_kernel<__bf16>, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
+  else if (bf16) hipLaunchKernelGGL(attn_fwd_bf16_kernel<float>, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(attn_fwd_kernel, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
   dx_prof_end(DX_PROF_ATTN_FWD, s);
   DX_LAUNCH_CHECK("dx_attention_fwd");
@@ -744,9 +780,12 @@ int dx_attention_fwd(const float* qkv, int ld, const int* lens, float* ctx, int 
 }
 
 // dqkv (all three thirds, every row) from dctx; `delta` is scratch [B][H][N]
-int dx_attention_bwd(const float* qkv, int ld, const float* ctx, const float* dctx, int ldc, const float* lse, float* delta,
-                     const int* lens, float* dqkv, int ldg, int B, int N, int H, int D, uint64_t seed, float p_drop, int bf16, void* stream) {
+int dx_attention_bwd(const void* qkvv, int ld, const float* ctx, const float* dctx, int ldc, const float* lse, float* delta,
+                     const int* lens, void* dqkvv, int ldg, int B, int N, int H, int D, uint64_t seed, float p_drop, int bf16,
+                     int qkv_bf16, int dqkv_bf16, void* stream) {
+  const float* qkv = (const float*)qkvv; float* dqkv = (float*)dqkvv;
   if (int rc = check_common("dx_attention_bwd", qkv, ld, B, N, H, D)) return rc;
+  DX_REQUIRE(!(qkv_bf16 || dqkv_bf16) || (bf16 && (ld % 8) == 0 && (ldg % 8) == 0), "dx_attention_bwd: bf16-stored qkv/dqkv need bf16 mode and ld %% 8 == 0");
   DX_REQUIRE(ctx && dctx && lse && delta && lens && dqkv, "dx_attention_bwd: null pointer");
   DX_REQUIRE(ldc >= D && (ldc % 4) == 0 && ldg >= 3 * D && (ldg % 4) == 0, "dx_attention_bwd: bad leading dimensions");
   DX_REQUIRE(((uintptr_t)dctx % 16) == 0 && ((uintptr_t)dqkv % 16) == 0, "dx_attention_bwd: pointers must be 16-byte aligned");
@@ -757,8 +796,15 @@ int dx_attention_bwd(const float* qkv, int ld, const float* ctx, const float* dc
   AttnBwdArgs a{qkv, ld, dctx, ldc, lse, delta, lens, dqkv, ldg, B, N, H, D, seed, (uint32_t)lrintf(p_drop * 65536.f), 1.f / (1.f - p_drop)};
   dx_prof_begin(DX_PROF_ATTN_BWD, s);
   if (bf16) {
-    hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
+    const dim3 grid(dx_cdiv(N, 64), H, B);
+#define DX_ATTN_BWD(QT_, OT_)                                                                          \
+    hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<QT_, OT_>), grid, dim3(256), 0, s, a);                 \
+    hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<QT_, OT_>), grid, dim3(256), 0, s, a);
+    if (qkv_bf16 && dqkv_bf16) { DX_ATTN_BWD(__bf16, __bf16) }
+    else if (qkv_bf16) { DX_ATTN_BWD(__bf16, float) }
+    else if (dqkv_bf16) { DX_ATTN_BWD(float, __bf16) }
+    else { DX_ATTN_BWD(float, float) }
+#undef DX_ATTN_BWD
   } else {
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);

@@ -146,7 +146,7 @@ class FFTBlockFn(torch.autograd.Function):
         s_attn, s_ln1, s_ln2 = (next_seed(), next_seed(), next_seed()) if training else (0, 0, 0)
         film = film if film is None or film.stride(-1) == 1 else film.contiguous()
         L = lens.i32
-        qkv = ops.conv_gemm(x, packs['in'], in_b, lens=L, halo=0)
+        qkv = ops.conv_gemm(x, packs['in'], in_b, lens=L, halo=0, out_dtype=ops.hidden_dtype())   # bf16 mode: attention reads bf16 q/k/v
         att, lse = ops.attention_fwd(qkv, lens.i32, heads, s_attn, p_attn)
         z1 = ops.conv_gemm(att, packs['out'], out_b, lens=L, halo=0)
         sh = ops.gemm_shadow()                     # bf16 mode: GEMM operands also exist as bf16 copies written by their producers
@@ -190,7 +190,7 @@ class FFTBlockFn(torch.autograd.Function):
         dproj = r1[5] if sh else (da1 if da1 is not None else dz1)
         dout_w, dout_b = ops.conv_wgrad(dproj, att, packs['out'], L, 0, arena=arena, w_sink=g('out_w'), b_sink=g('out_b'))
         datt = ops.conv_gemm(dproj, packs['out'], None, transpose=True, lens=L, halo=0)
-        dqkv = ops.attention_bwd(qkv, att, datt, lse, L, ctx.heads, s_attn, p_attn)
+        dqkv = ops.attention_bwd(qkv, att, datt, lse, L, ctx.heads, s_attn, p_attn, out_dtype=qkv.dtype)
         din_w, din_b = ops.conv_wgrad(dqkv, x, packs['in'], L, 0, arena=arena, w_sink=g('in_w'), b_sink=g('in_b'))
         dx = ops.conv_gemm(dqkv, packs['in'], None, transpose=True, out=dz1, accumulate=True, lens=L, halo=0)  # + residual branch
         return (dx, dfilm, None, None, None, None,

@@ -241,17 +241,18 @@ def attention_fwd(qkv, lens, heads, seed, p_drop):
     D = D3 // 3
     ctx = torch.empty(B, N, D, dtype=torch.float32, device=qkv.device)
     lse = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device)
-    lib().dx_attention_fwd(_p(qkv), _rows(qkv), _p(lens), _p(ctx), D, _p(lse), B, N, heads, D, seed, float(p_drop), _PRECISION['bf16'], _stream())
+    lib().dx_attention_fwd(_p(qkv), _rows(qkv), _p(lens), _p(ctx), D, _p(lse), B, N, heads, D, seed, float(p_drop), _PRECISION['bf16'],
+                           _is_bf16(qkv), _stream())
     return ctx, lse
 
 
-def attention_bwd(qkv, ctx, dctx, lse, lens, heads, seed, p_drop):
+def attention_bwd(qkv, ctx, dctx, lse, lens, heads, seed, p_drop, out_dtype=torch.float32):
     B, N, D3 = qkv.shape
     D = D3 // 3
-    dqkv = torch.empty_like(qkv)
+    dqkv = torch.empty(B, N, D3, dtype=out_dtype, device=qkv.device)
     delta = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device)
     lib().dx_attention_bwd(_p(qkv), _rows(qkv), _p(ctx), _p(dctx), _rows(dctx), _p(lse), _p(delta), _p(lens), _p(dqkv), _rows(dqkv),
-                           B, N, heads, D, seed, float(p_drop), _PRECISION['bf16'], _stream())
+                           B, N, heads, D, seed, float(p_drop), _PRECISION['bf16'], _is_bf16(qkv), _is_bf16(dqkv), _stream())
     return dqkv
 
 
