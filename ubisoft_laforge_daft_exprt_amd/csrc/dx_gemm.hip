@@ -24,7 +24,6 @@
 // zero, which is exactly the reference's zero 'same' padding on the padded (B, N_max) grid.
 #include "dx_common.h"
 #include <algorithm>
-#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -699,35 +698,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBf16Args 
   const bool do_bias = a.dbias != nullptr && ci0 == 0 && tid < TILE;
   float bsum = 0.f;
   f32x4 dreg[D_IT], xreg[X_IT];
-  // thread-invariant parts of the prefetch addresses, hoisted out of the chunk loop (the per-load 64-bit address arithmetic
-  // and predication were ~2 k of a chunk's 4.5 k cycles): element offset inside the chunk, row inside the chunk, channel validity
-  int d_off[D_IT], d_row[D_IT], x_off[X_IT], x_row[X_IT];
-  bool d_ok[D_IT], x_ok[X_IT];
-#pragma unroll
-  for (int it = 0; it < D_IT; ++it) {
-    const int u = tid + it * 256, row = u / DU, q = u % DU, c = co0 + q * DE;
-    d_row[it] = row; d_ok[it] = c < a.Cout; d_off[it] = row * a.ldy + c;
-  }
-#pragma unroll
-  for (int it = 0; it < X_IT; ++it) {
-    const int u = tid + it * 256, row = u / XU, q = u % XU, c = ci0 + q * XE;
-    x_row[it] = row - PAD; x_ok[it] = u < XROWS * XU && c < a.Cin; x_off[it] = (row - PAD) * a.ldx + c;
-  }
-  using DT = typename std::conditional<DYH, __bf16, float>::type;
-  using XT = typename std::conditional<XH, __bf16, float>::type;
 #define DX_WG_LOAD(B_, NC_)                                                                                                   \
   {                                                                                                                           \
-    const DT* dbase_ = reinterpret_cast<const DT*>(a.dY) + ((size_t)(B_) * a.N + (NC_)) * a.ldy;                              \
-    const XT* xbase_ = reinterpret_cast<const XT*>(a.X) + ((size_t)(B_) * a.N + (NC_)) * a.ldx;                               \
     _Pragma("unroll") for (int it = 0; it < D_IT; ++it) {                                                                     \
+      const int u = tid + it * 256;                                                                                           \
+      const int row = u / DU, q = u % DU;                                                                                     \
+      const int n = (NC_) + row, c = co0 + q * DE;                                                                            \
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                                                    \
-      if (d_ok[it] && (NC_) + d_row[it] < a.N) v = *reinterpret_cast<const f32x4*>(dbase_ + d_off[it]);                       \
+      if (n < a.N && c < a.Cout) {                                                                                            \
+        if constexpr (DYH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.dY) + ((size_t)(B_) * a.N + n) * a.ldy + c); \
+        else v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.dY) + ((size_t)(B_) * a.N + n) * a.ldy + c); \
+      }                                                                                                                       \
       dreg[it] = v;                                                                                                           \
     }                                                                                                                         \
     _Pragma("unroll") for (int it = 0; it < X_IT; ++it) {                                                                     \
-      const int n = (NC_) + x_row[it];                                                                                        \
+      const int u = tid + it * 256;                                                                                           \
+      const int row = u / XU, q = u % XU;                                                                                     \
+      const int n = (NC_) - PAD + row, c = ci0 + q * XE;                                                                      \
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                                                    \
-      if (x_ok[it] && n >= 0 && n < a.N) v = *reinterpret_cast<const f32x4*>(xbase_ + x_off[it]);                             \
+      if (u < XROWS * XU && n >= 0 && n < a.N && c < a.Cin) {                                                                 \
+        if constexpr (XH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.X) + ((size_t)(B_) * a.N + n) * a.ldx + c); \
+        else v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.X) + ((size_t)(B_) * a.N + n) * a.ldx + c); \
+      }                                                                                                                       \
       xreg[it] = v;                                                                                                           \
     }                                                                                                                         \
   }
