@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a)
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = expf(m_run - m_new);
+    const float alpha = __expf(m_run - m_new);
     float ls = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a)
       if (a.thresh) dx_dropout_scale4(a.seed, drop_index(bh, a.N, qrow, kbase + kt * 16 + g * 4), a.thresh, a.inv_keep, keep);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float p = expf(st[kt][e] - m_new);
+        const float p = __expf(st[kt][e] - m_new);
         ls += p;
         st[kt][e] = p * keep[e];
       }
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const bool masked = kbase + kt * 16 + g * 4 + e >= len;
-        const float p = masked ? 0.f : expf(s[e] - lse_q);
+        const float p = masked ? 0.f : __expf(s[e] - lse_q);
         s[e] = p * (dp[e] * keep[e] - delta_q) * QSCALE;
       }
       ds[kt] = s;
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwd
       for (int e = 0; e < 4; ++e) {
         const int ql = qt * 16 + g * 4 + e, q = qbase + ql;
         const bool live = key_valid && q < len;
-        const float p = live ? expf(s[e] - lse_s[ql]) : 0.f;
+        const float p = live ? __expf(s[e] - lse_s[ql]) : 0.f;
         float keep = 1.f;
         if (a.thresh) keep = dx_dropout_scale(a.seed, drop_index(bh, a.N, q, krow), a.thresh, a.inv_keep);
         pd[qt][e] = p * keep;
