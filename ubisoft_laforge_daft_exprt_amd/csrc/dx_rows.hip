@@ -30,122 +30,117 @@ struct LnArgs {
   uint64_t seed_post; uint32_t thresh_post; float inv_keep_post;  // dropout on LN output
 };
 
+// Row layout in a wave: LPR lanes share one row and a wave walks 64/LPR rows at once.  C = 128 rows are only 512 bytes,
+// so one row per wave-instruction leaves the memory pipe mostly idle; 16 lanes x two 16-byte accesses per row puts
+// four rows (2 KB per tensor) in flight per wave.  C = 1024 keeps the whole wave on one row.
 template <int C> struct RowVec {
-  static constexpr int V = (C >= 256) ? 4 : 2;          // floats per access
-  static constexpr int K = C / (64 * V);                // accesses per lane
-  static_assert(C % (64 * V) == 0, "C must be a multiple of 128");
+  static constexpr int V = 4;                           // floats per access
+  static constexpr int LPR = (C >= 256) ? 64 : 16;      // lanes per row
+  static constexpr int RPW = 64 / LPR;                  // rows per wave
+  static constexpr int K = C / (LPR * V);               // accesses per lane
+  static constexpr int E = K * V;
+  static_assert(C % (LPR * V) == 0, "C must be a multiple of 64");
 };
 
+// p = base of the lane's row, l = lane % LPR
 template <int C>
-__device__ __forceinline__ void row_load(const float* p, int lane, float v[RowVec<C>::K * RowVec<C>::V]) {
-  constexpr int V = RowVec<C>::V, K = RowVec<C>::K;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const int c = (k * 64 + lane) * V;
-    if constexpr (V == 4) {
-      const float4 t = *reinterpret_cast<const float4*>(p + c);
-      v[k * 4 + 0] = t.x; v[k * 4 + 1] = t.y; v[k * 4 + 2] = t.z; v[k * 4 + 3] = t.w;
-    } else {
-      const float2 t = *reinterpret_cast<const float2*>(p + c);
-      v[k * 2 + 0] = t.x; v[k * 2 + 1] = t.y;
-    }
-  }
-}
-template <int C>
-__device__ __forceinline__ void row_store(float* p, int lane, const float v[RowVec<C>::K * RowVec<C>::V]) {
-  constexpr int V = RowVec<C>::V, K = RowVec<C>::K;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const int c = (k * 64 + lane) * V;
-    if constexpr (V == 4) *reinterpret_cast<float4*>(p + c) = make_float4(v[k * 4], v[k * 4 + 1], v[k * 4 + 2], v[k * 4 + 3]);
-    else *reinterpret_cast<float2*>(p + c) = make_float2(v[k * 2], v[k * 2 + 1]);
-  }
-}
-// bf16-stored rows (the 1024-wide prenet activations in bf16 operand mode): same lane -> column map, 8-byte accesses
-template <int C>
-__device__ __forceinline__ void row_load(const __bf16* p, int lane, float v[RowVec<C>::K * RowVec<C>::V]) {
-  static_assert(RowVec<C>::V == 4, "bf16 rows need C >= 256");
+__device__ __forceinline__ void row_load(const float* p, int l, float v[RowVec<C>::E]) {
 #pragma unroll
   for (int k = 0; k < RowVec<C>::K; ++k) {
-    const bf16x4 t = *reinterpret_cast<const bf16x4*>(p + (k * 64 + lane) * 4);
+    const float4 t = *reinterpret_cast<const float4*>(p + (k * RowVec<C>::LPR + l) * 4);
+    v[k * 4 + 0] = t.x; v[k * 4 + 1] = t.y; v[k * 4 + 2] = t.z; v[k * 4 + 3] = t.w;
+  }
+}
+template <int C>
+__device__ __forceinline__ void row_store(float* p, int l, const float v[RowVec<C>::E]) {
+#pragma unroll
+  for (int k = 0; k < RowVec<C>::K; ++k)
+    *reinterpret_cast<float4*>(p + (k * RowVec<C>::LPR + l) * 4) = make_float4(v[k * 4], v[k * 4 + 1], v[k * 4 + 2], v[k * 4 + 3]);
+}
+// bf16-stored rows: same lane -> column map, 8-byte accesses
+template <int C>
+__device__ __forceinline__ void row_load(const __bf16* p, int l, float v[RowVec<C>::E]) {
+#pragma unroll
+  for (int k = 0; k < RowVec<C>::K; ++k) {
+    const bf16x4 t = *reinterpret_cast<const bf16x4*>(p + (k * RowVec<C>::LPR + l) * 4);
     v[k * 4 + 0] = (float)t[0]; v[k * 4 + 1] = (float)t[1]; v[k * 4 + 2] = (float)t[2]; v[k * 4 + 3] = (float)t[3];
   }
 }
 template <int C>
-__device__ __forceinline__ void row_store(__bf16* p, int lane, const float v[RowVec<C>::K * RowVec<C>::V]) {
-  static_assert(RowVec<C>::V == 4, "bf16 rows need C >= 256");
+__device__ __forceinline__ void row_store(__bf16* p, int l, const float v[RowVec<C>::E]) {
 #pragma unroll
   for (int k = 0; k < RowVec<C>::K; ++k) {
     bf16x4 t;
     t[0] = (__bf16)v[k * 4]; t[1] = (__bf16)v[k * 4 + 1]; t[2] = (__bf16)v[k * 4 + 2]; t[3] = (__bf16)v[k * 4 + 3];
-    *reinterpret_cast<bf16x4*>(p + (k * 64 + lane) * 4) = t;
+    *reinterpret_cast<bf16x4*>(p + (k * RowVec<C>::LPR + l) * 4) = t;
   }
 }
-template <int C> __device__ __forceinline__ int row_col(int lane, int idx) {
-  constexpr int V = RowVec<C>::V;
-  return ((idx / V) * 64 + lane) * V + (idx % V);
+template <int C> __device__ __forceinline__ int row_col(int l, int idx) {
+  return ((idx / 4) * RowVec<C>::LPR + l) * 4 + (idx % 4);
+}
+// sum over the LPR lanes that share a row (every lane of the group gets the total)
+template <int C> __device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+  for (int off = RowVec<C>::LPR / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
 }
 
 template <int C, typename IO>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
-  constexpr int E = RowVec<C>::K * RowVec<C>::V;
+  constexpr int E = RowVec<C>::E, LPR = RowVec<C>::LPR, RPW = RowVec<C>::RPW;
   IO* const A = reinterpret_cast<IO*>(a.a);
   const IO* const R = reinterpret_cast<const IO*>(a.res);
   IO* const Y = reinterpret_cast<IO*>(a.y);
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, l = lane % LPR, sub = lane / LPR;
   const long rows = (long)a.B * a.N;
-  for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
-    const int b = (int)(row / a.N), n = (int)(row - (long)b * a.N);
-    const bool valid = !a.lens || n < a.lens[b] + a.halo;
+  float wv[E], bv[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) { wv[e] = a.w[row_col<C>(l, e)]; bv[e] = a.bias[row_col<C>(l, e)]; }
+  // the loop bound is wave-uniform; lanes whose row is out of range or padded run the arithmetic on zeros
+  for (long base = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW; base < rows; base += (long)gridDim.x * 4 * RPW) {
+    const long row = base + sub;
+    const bool inb = row < rows;
+    const int b = inb ? (int)(row / a.N) : 0, n = inb ? (int)(row - (long)b * a.N) : 0;
+    const bool valid = inb && (!a.lens || n < a.lens[b] + a.halo);
     float z[E];
-    if (!valid) {
-      // padded row: the output is zero by definition and nothing reads z / mean / rstd of it (the backward skips it too);
-      // keep them defined without touching the inputs
 #pragma unroll
-      for (int e = 0; e < E; ++e) z[e] = 0.f;
-      row_store<C>(Y + row * C, lane, z);
-      if constexpr (sizeof(IO) == 4 && C < 256) { if (a.y_h) *reinterpret_cast<unsigned*>(a.y_h + row * C + lane * 2) = 0u; }
-      if (a.thresh_pre || a.res) row_store<C>(A + row * C, lane, z);
-      if (lane == 0) { a.mean[row] = 0.f; a.rstd[row] = 0.f; }
-      continue;
-    }
-    row_load<C>(A + row * C, lane, z);
-    if (a.thresh_pre) {
+    for (int e = 0; e < E; ++e) z[e] = 0.f;
+    if (valid) {
+      row_load<C>(A + row * C, l, z);
+      if (a.thresh_pre) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) z[e] *= dx_dropout_scale(a.seed_pre, (uint64_t)row * C + row_col<C>(lane, e), a.thresh_pre, a.inv_keep_pre);
-    }
-    if (a.res) {
-      float rv[E];
-      row_load<C>(R + row * C, lane, rv);
+        for (int e = 0; e < E; ++e) z[e] *= dx_dropout_scale(a.seed_pre, (uint64_t)row * C + row_col<C>(l, e), a.thresh_pre, a.inv_keep_pre);
+      }
+      if (a.res) {
+        float rv[E];
+        row_load<C>(R + row * C, l, rv);
 #pragma unroll
-      for (int e = 0; e < E; ++e) z[e] += rv[e];
+        for (int e = 0; e < E; ++e) z[e] += rv[e];
+      }
     }
-    if (a.thresh_pre || a.res) row_store<C>(A + row * C, lane, z);
+    // padded rows: the output is zero by definition and nothing reads z / mean / rstd of them (the backward skips them too)
+    if (inb && (a.thresh_pre || a.res)) row_store<C>(A + row * C, l, z);
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < E; ++e) s += z[e];
-    const float mu = dx_wave_sum(s) * (1.0f / C);
+    const float mu = row_sum<C>(s) * (1.0f / C);
     float q = 0.f;
 #pragma unroll
     for (int e = 0; e < E; ++e) { const float d = z[e] - mu; q += d * d; }
-    const float rs = 1.0f / sqrtf(dx_wave_sum(q) * (1.0f / C) + LN_EPS);
-    if (lane == 0) { a.mean[row] = mu; a.rstd[row] = rs; }
+    const float rs = 1.0f / sqrtf(row_sum<C>(q) * (1.0f / C) + LN_EPS);
+    if (inb && l == 0) { a.mean[row] = valid ? mu : 0.f; a.rstd[row] = valid ? rs : 0.f; }
     float y[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const int c = row_col<C>(lane, e);
-      float t = (z[e] - mu) * rs * a.w[c] + a.bias[c];
+      const int c = row_col<C>(l, e);
+      float t = (z[e] - mu) * rs * wv[e] + bv[e];
       if (a.thresh_post) t *= dx_dropout_scale(a.seed_post, (uint64_t)row * C + c, a.thresh_post, a.inv_keep_post);
       if (a.film) t = a.film[(size_t)b * a.ld_film + c] * t + a.film[(size_t)b * a.ld_film + C + c];
       y[e] = valid ? t : 0.f;
     }
-    row_store<C>(Y + row * C, lane, y);
-    if constexpr (sizeof(IO) == 4 && C < 256) {
-      if (a.y_h) {
-        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-        bf16x2_t h2; h2[0] = (__bf16)y[0]; h2[1] = (__bf16)y[1];
-        *reinterpret_cast<bf16x2_t*>(a.y_h + row * C + lane * 2) = h2;
-      }
+    if (inb) {
+      row_store<C>(Y + row * C, l, y);
+      if constexpr (sizeof(IO) == 4 && C < 256) { if (a.y_h) row_store<C>(a.y_h + row * C, l, y); }
     }
   }
 }
@@ -167,86 +162,89 @@ struct LnBwdArgs {
   uint64_t seed_post; uint32_t thresh_post; float inv_keep_post;
 };
 
-// grid: (blocks per batch row, B); each wave walks rows of ONE batch row so FiLM gradients reduce per b.
-template <int C, typename IO>
+// grid: (blocks per batch row, B); each block walks rows of ONE batch row so FiLM gradients reduce per b.
+template <int C, typename IO, bool FILM>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
-  constexpr int E = RowVec<C>::K * RowVec<C>::V;
+  constexpr int E = RowVec<C>::E, LPR = RowVec<C>::LPR, RPW = RowVec<C>::RPW;
   const IO* const DY = reinterpret_cast<const IO*>(a.dy);
   const IO* const Z = reinterpret_cast<const IO*>(a.z);
   IO* const DZ = reinterpret_cast<IO*>(a.dz);
   IO* const DA = reinterpret_cast<IO*>(a.da);
   __shared__ float red[4][C];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane % LPR, sub = lane / LPR;
   const int b = blockIdx.y;
   const int n_begin = blockIdx.x * a.rows_per_block;
   const int n_end = min(a.N, n_begin + a.rows_per_block);
-  const int len_b = a.lens ? a.lens[b] + a.halo : a.N;
-  float gw[E], gb[E], gfg[E], gfb[E];
+  const int len_b = min(a.lens ? a.lens[b] + a.halo : a.N, a.N);
+  constexpr int EF = FILM ? E : 1;                      // FiLM accumulators only where a FiLM follows the LayerNorm
+  float gw[E], gb[E], gfg[EF], gfb[EF];
 #pragma unroll
-  for (int e = 0; e < E; ++e) gw[e] = gb[e] = gfg[e] = gfb[e] = 0.f;
-  float wv[E], bv[E], fg[E];
+  for (int e = 0; e < E; ++e) gw[e] = gb[e] = 0.f;
+#pragma unroll
+  for (int e = 0; e < EF; ++e) gfg[e] = gfb[e] = 0.f;
+  float wv[E], bv[E], fg[EF];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    const int c = row_col<C>(lane, e);
+    const int c = row_col<C>(l, e);
     wv[e] = a.w[c]; bv[e] = a.bias[c];
-    fg[e] = a.film ? a.film[(size_t)b * a.ld_film + c] : 1.f;
+    if constexpr (FILM) fg[e] = a.film[(size_t)b * a.ld_film + c];
   }
-  for (int n = n_begin + wave; n < n_end; n += 4) {
+  for (int n0 = n_begin + wave * RPW; n0 < n_end; n0 += 4 * RPW) {      // wave-uniform bound
+    const int n = n0 + sub;
     const long row = (long)b * a.N + n;
-    float dzv[E];
-    if (n >= len_b) {
+    const bool inb = n < n_end, valid = inb && n < len_b;
+    float dy[E], z[E], dzv[E];
 #pragma unroll
-      for (int e = 0; e < E; ++e) dzv[e] = 0.f;
-      row_store<C>(DZ + row * C, lane, dzv);
-      if (a.da) row_store<C>(DA + row * C, lane, dzv);
-      if constexpr (sizeof(IO) == 4 && C < 256) { if (a.dg_h) *reinterpret_cast<unsigned*>(a.dg_h + row * C + lane * 2) = 0u; }
-      continue;
+    for (int e = 0; e < E; ++e) { dy[e] = 0.f; z[e] = 0.f; }
+    float mu = 0.f, rs = 0.f;
+    if (valid) {
+      row_load<C>(DY + row * C, l, dy);
+      row_load<C>(Z + row * C, l, z);
+      mu = a.mean[row]; rs = a.rstd[row];
     }
-    float dy[E], z[E];
-    row_load<C>(DY + row * C, lane, dy);
-    row_load<C>(Z + row * C, lane, z);
-    const float mu = a.mean[row], rs = a.rstd[row];
     float s1 = 0.f, s2 = 0.f, g[E], xh[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const int c = row_col<C>(lane, e);
+      const int c = row_col<C>(l, e);
       xh[e] = (z[e] - mu) * rs;
       float ln = xh[e] * wv[e] + bv[e];                 // LayerNorm output (before post-dropout / FiLM)
-      float d = dy[e];
+      float d = dy[e];                                  // zero on padded / out-of-range rows: they add nothing below
       float post = 1.f;
       if (a.thresh_post) post = dx_dropout_scale(a.seed_post, (uint64_t)row * C + c, a.thresh_post, a.inv_keep_post);
-      if (a.film) { gfg[e] += d * ln * post; gfb[e] += d; d *= fg[e]; }
+      if constexpr (FILM) { gfg[e] += d * ln * post; gfb[e] += d; d *= fg[e]; }
       d *= post;                                        // gradient w.r.t. LN output
       gw[e] += d * xh[e]; gb[e] += d;
       g[e] = d * wv[e];
       s1 += g[e]; s2 += g[e] * xh[e];
     }
-    s1 = dx_wave_sum(s1) * (1.0f / C);
-    s2 = dx_wave_sum(s2) * (1.0f / C);
+    s1 = row_sum<C>(s1) * (1.0f / C);
+    s2 = row_sum<C>(s2) * (1.0f / C);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       dzv[e] = rs * (g[e] - s1 - xh[e] * s2);
       if (a.relu_mask && !(z[e] > 0.f)) dzv[e] = 0.f;
     }
-    row_store<C>(DZ + row * C, lane, dzv);
+    if (!inb) continue;                                 // no cross-lane traffic below this point
+    row_store<C>(DZ + row * C, l, dzv);
     if ((a.da || a.dg_h) && a.thresh_pre) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) dzv[e] *= dx_dropout_scale(a.seed_pre, (uint64_t)row * C + row_col<C>(lane, e), a.thresh_pre, a.inv_keep_pre);
+      for (int e = 0; e < E; ++e) dzv[e] *= dx_dropout_scale(a.seed_pre, (uint64_t)row * C + row_col<C>(l, e), a.thresh_pre, a.inv_keep_pre);
     }
-    if (a.da) row_store<C>(DA + row * C, lane, dzv);
-    if constexpr (sizeof(IO) == 4 && C < 256) {
-      if (a.dg_h) {
-        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-        bf16x2_t h2; h2[0] = (__bf16)dzv[0]; h2[1] = (__bf16)dzv[1];
-        *reinterpret_cast<bf16x2_t*>(a.dg_h + row * C + lane * 2) = h2;
-      }
-    }
+    if (a.da) row_store<C>(DA + row * C, l, dzv);
+    if constexpr (sizeof(IO) == 4 && C < 256) { if (a.dg_h) row_store<C>(a.dg_h + row * C, l, dzv); }
   }
-  // block reduction of the per-channel sums, then one atomic per channel per block
+  // per-channel sums: fold the row groups of a wave, then the waves through LDS, then one atomic per channel per block
   auto reduce_and_add = [&](float* vals, float* dst) {
-    __syncthreads();
 #pragma unroll
-    for (int e = 0; e < E; ++e) red[wave][row_col<C>(lane, e)] = vals[e];
+    for (int e = 0; e < E; ++e) {
+#pragma unroll
+      for (int off = LPR; off < 64; off <<= 1) vals[e] += __shfl_xor(vals[e], off, 64);
+    }
+    __syncthreads();
+    if (sub == 0) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) red[wave][row_col<C>(l, e)] = vals[e];
+    }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
       const float s = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
@@ -255,7 +253,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
   };
   reduce_and_add(gw, a.dw);
   reduce_and_add(gb, a.dbias);
-  if (a.dfilm) {
+  if constexpr (FILM) {
     reduce_and_add(gfg, a.dfilm + (size_t)b * a.ld_dfilm);
     reduce_and_add(gfb, a.dfilm + (size_t)b * a.ld_dfilm + C);
   }
@@ -548,7 +546,7 @@ int dx_ln_fwd(void* av, const void* resv, const float* w, const float* bias, con
   hipStream_t s = (hipStream_t)stream;
   dx_prof_begin(DX_PROF_ROWS, s);
   const int grid = row_grid((long)B * N);
-  if (C == 128) hipLaunchKernelGGL((ln_fwd_kernel<128, float>), dim3(grid), dim3(256), 0, s, k);
+  if (C == 128) hipLaunchKernelGGL((ln_fwd_kernel<128, float>), dim3(dx_cdiv(grid, RowVec<128>::RPW)), dim3(256), 0, s, k);
   else if (io_bf16) hipLaunchKernelGGL((ln_fwd_kernel<1024, __bf16>), dim3(grid), dim3(256), 0, s, k);
   else hipLaunchKernelGGL((ln_fwd_kernel<1024, float>), dim3(grid), dim3(256), 0, s, k);
   dx_prof_end(DX_PROF_ROWS, s);
@@ -573,9 +571,13 @@ int dx_ln_bwd(const void* dyv, const void* zv, const float* mean, const float* r
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(dx_cdiv(N, rpb), B);
   dx_prof_begin(DX_PROF_ROWS, s);
-  if (C == 128) hipLaunchKernelGGL((ln_bwd_kernel<128, float>), grid, dim3(256), 0, s, k);
-  else if (io_bf16) hipLaunchKernelGGL((ln_bwd_kernel<1024, __bf16>), grid, dim3(256), 0, s, k);
-  else hipLaunchKernelGGL((ln_bwd_kernel<1024, float>), grid, dim3(256), 0, s, k);
+#define DX_LN_BWD(CC, IO) do { \
+    if (film) hipLaunchKernelGGL((ln_bwd_kernel<CC, IO, true>), grid, dim3(256), 0, s, k); \
+    else hipLaunchKernelGGL((ln_bwd_kernel<CC, IO, false>), grid, dim3(256), 0, s, k); } while (0)
+  if (C == 128) DX_LN_BWD(128, float);
+  else if (io_bf16) DX_LN_BWD(1024, __bf16);
+  else DX_LN_BWD(1024, float);
+#undef DX_LN_BWD
   dx_prof_end(DX_PROF_ROWS, s);
   DX_LAUNCH_CHECK("dx_ln_bwd");
   return DX_OK;
