@@ -162,6 +162,45 @@ def test_weight_stationary_conv_path(ops, Cin, Cout, taps):
         ops.set_precision('f32')
 
 
+@pytest.mark.parametrize('Cin,Cout,taps,x_bf16', [(1024, 128, 3, True), (1024, 128, 3, False), (320, 256, 3, True), (256, 384, 1, False),
+                                                   (1024, 80, 1, True), (448, 1024, 3, True)])
+def test_deep_k_conv_path(ops, Cin, Cout, taps, x_bf16):
+    """bf16 layers with Cin >= 256 run the staggered two-waves-per-SIMD kernel (K split inside the workgroup, LDS double buffer):
+    odd and even stage counts, both activation storage types, every epilogue variant, tile skipping."""
+    ops.set_precision('bf16')
+    try:
+        B, N = 4, 300                                        # 3 token tiles per row, ragged last tile
+        lens = lens_tensor([300, 257, 128, 5])
+        wshape = (Cout, Cin, 3) if taps == 3 else (Cout, Cin)
+        w = randn(*wshape, seed=1, scale=1.0 / math.sqrt(Cin * taps))
+        b = randn(Cout, seed=2, scale=0.1)
+        x = randn(B, N, Cin, seed=3)
+        xin = x.to(torch.bfloat16) if x_bf16 else x
+        xr = xin.float()
+        pack = ops.PackedWeight(w)
+        ref = ref_conv(xr, w, b, taps)
+        assert rel_err(ops.conv_gemm(xin, pack, b), ref) < 1e-2
+        valid = (torch.arange(N, device=DEV)[None, :] < lens[:, None])[:, :, None]
+        y = ops.conv_gemm(xin, pack, b, lens=lens, mask_rows=True, halo=0)
+        assert rel_err(y, ref * valid) < 1e-2 and torch.equal(y * ~valid, torch.zeros_like(y))
+        if Cout % 8 == 0:
+            aux = randn(B, N, Cout, seed=4).to(torch.bfloat16)
+            sc, sh = 1 + 0.1 * randn(Cout, seed=5), 0.1 * randn(Cout, seed=7)
+            yb = ops.conv_gemm(xin, pack, b, relu=True, post_scale=sc, post_shift=sh, relu_aux=aux, lens=lens, halo=1, out_dtype=torch.bfloat16,
+                               out_scale=0.5)
+            refb = (F.relu(ref) * sc + sh) * 0.5 * (aux.float() > 0)
+            keep = (torch.arange(N, device=DEV)[None, :, None] < ((lens[:, None, None] + 1 + 127) // 128) * 128)
+            assert yb.dtype == torch.bfloat16 and rel_err(yb.float() * keep, refb * keep) < 2e-2
+            assert torch.equal(yb.float() * ~keep, torch.zeros_like(refb))
+        acc0 = randn(B, N, Cout, seed=6)
+        ya = ops.conv_gemm(xin, pack, None, out=acc0.clone(), accumulate=True, lens=lens, halo=0)
+        tiles_ok = (torch.arange(N, device=DEV)[None, :, None] < ((lens[:, None, None] + 127) // 128) * 128)
+        assert rel_err(ya * tiles_ok, (acc0 + ref_conv(xr, w, None, taps)) * tiles_ok) < 1e-2
+        assert torch.equal(ya * ~tiles_ok, acc0 * ~tiles_ok)
+    finally:
+        ops.set_precision('f32')
+
+
 def ref_attention(qkv, lens, heads, keep=None, p=0.0):
     B, N, D3 = qkv.shape
     D = D3 // 3

@@ -78,6 +78,25 @@ __device__ __forceinline__ uint2 pack_bf16x4(const float4& v) {
 // tile needs 65 KB instead of 74 KB (two workgroups per CU with room to spare).
 __device__ __forceinline__ int lds_off(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
 
+// bf16 weight packs are fragment-major: the [rows][K] matrix of a tap is cut into 16-row x 32-k blocks, each stored as the
+// 64 x 8 elements one v_mfma_f32_16x16x32_bf16 "A" operand takes (lane = (k / 8 % 4) * 16 + row % 16, 8 consecutive k per lane).
+// A wave reads a whole fragment with one contiguous 1 KB load; kernels that stage weights through LDS fetch the same 16-byte
+// units (wb_off is a multiple of 8 for k % 8 == 0).  rowsP % 16 == 0, kP % 32 == 0.
+__device__ __forceinline__ size_t wb_off(int tap, int row, int k, int rowsP, int kP) {
+  return ((size_t)(tap * (rowsP >> 4) + (row >> 4)) * (kP >> 5) + (k >> 5)) * 512 + ((((k >> 3) & 3) << 4) + (row & 15)) * 8 + (k & 7);
+}
+// staging slot u of a [tap][128 rows][64 k] weight tile -> (tile row, 16-byte slot): consecutive lanes walk one block of the
+// fragment-major pack (bf16, contiguous 1 KB per wave-instruction) or one row (f32)
+template <typename T> __device__ __forceinline__ void w_unit(int u, int& row, int& q) {
+  if constexpr (sizeof(T) == 2) {
+    const int v = u & 1023;
+    row = (u >> 10) * TILE + (v >> 7) * 16 + (v & 15);
+    q = ((v >> 6) & 1) * 4 + ((v >> 4) & 3);
+  } else {
+    row = u >> 3; q = u & 7;
+  }
+}
+
 // TOK = tokens per workgroup (128, or 64 for narrow outputs that would otherwise launch fewer workgroups than CUs).
 // XH  = the activation tensor is stored as bf16 (bf16 operand mode only).
 // Software pipeline: the global loads of K-chunk c+1 are issued into registers before the MFMAs of chunk c and written
@@ -133,10 +152,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
   {                                                                                                                              \
     const int ci0_ = (CH) * BK;                                                                                                  \
     _Pragma("unroll") for (int it = 0; it < W_IT; ++it) {                                                                        \
-      const int u = tid + it * 256;                                                                                              \
-      const int row = u >> 3, q = u & 7;                                                                                         \
+      int row, q;                                                                                                                \
+      w_unit<T>(tid + it * 256, row, q);                                                                                         \
       const int tap = row >> 7, col = row & (TILE - 1);                                                                          \
-      wreg[it] = *reinterpret_cast<const f32x4*>(Wp + ((size_t)(tap * a.CoutP + co0 + col) * a.CinP + ci0_) + q * (16 / (int)sizeof(T))); \
+      if constexpr (sizeof(T) == 2) wreg[it] = *reinterpret_cast<const f32x4*>(Wp + wb_off(tap, co0 + col, ci0_ + q * 8, a.CoutP, a.CinP)); \
+      else wreg[it] = *reinterpret_cast<const f32x4*>(Wp + ((size_t)(tap * a.CoutP + co0 + col) * a.CinP + ci0_) + q * 4);       \
     }                                                                                                                            \
     _Pragma("unroll") for (int it = 0; it < X_IT; ++it) {                                                                        \
       const int u = tid + it * 256;                                                                                              \
@@ -153,8 +173,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
 #define DX_STORE_CHUNK()                                                                                                         \
   {                                                                                                                              \
     _Pragma("unroll") for (int it = 0; it < W_IT; ++it) {                                                                        \
-      const int u = tid + it * 256;                                                                                              \
-      *reinterpret_cast<f32x4*>(Ws + lds_off(u >> 3, u & 7)) = wreg[it];                                                        \
+      int row, q;                                                                                                                \
+      w_unit<T>(tid + it * 256, row, q);                                                                                         \
+      *reinterpret_cast<f32x4*>(Ws + lds_off(row, q)) = wreg[it];                                                               \
     }                                                                                                                            \
     _Pragma("unroll") for (int it = 0; it < X_IT; ++it) {                                                                        \
       const int u = tid + it * 256;                                                                                              \
@@ -301,11 +322,11 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, i
 
   // weight slice -> LDS, once
   for (int u = tid; u < W_ROWS * 8; u += 512) {
-    const int row = u >> 3, q = u & 7;
+    int row, q;
+    w_unit<__bf16>(u, row, q);
     const int ch = row / (TAPS * TILE), rem = row - ch * (TAPS * TILE);
     const int tap = rem >> 7, col = rem & (TILE - 1);
-    *reinterpret_cast<f32x4*>(Ws + lds_off(row, q)) =
-        *reinterpret_cast<const f32x4*>(Wp + ((size_t)(tap * a.CoutP + co0 + col) * a.CinP + ch * 64) + q * 8);
+    *reinterpret_cast<f32x4*>(Ws + lds_off(row, q)) = *reinterpret_cast<const f32x4*>(Wp + wb_off(tap, co0 + col, ch * 64 + q * 8, a.CoutP, a.CinP));
   }
 
   const int tiles_n = (a.N + TOK - 1) / TOK;
@@ -529,6 +550,315 @@ void launch_conv_ws(const ConvGemmArgs& a, hipStream_t s) {
   const int per_cu = smem * 2 <= 160 * 1024 ? 2 : 1;       // TAPS=1 fits twice per CU
   const int wgs = std::max(1, std::min(total, (256 * per_cu) / co_tiles));
   hipLaunchKernelGGL((conv_ws_kernel<TAPS, XH>), dim3(wgs, co_tiles), dim3(512), smem, s, a, wgs);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Deep-K variant (bf16 operands, CinP >= 256: FF conv2 1024 -> 128, the input gradient of FF conv1, the 1024-wide prenet
+// convs).  With Cout = 128 these launches have at most ~one workgroup per CU and a 16-48 stage K loop, so they run at the
+// latency of ONE workgroup's loop, and in the tiled kernel that loop is dominated by moving the weight tile: 49 of the 65 KB
+// staged per 64-deep stage are weights, written to LDS at ~79 B/clk (13 cycles per ds_write_b128) and read back as fragments.
+// Here the weights never touch LDS: the bf16 pack is fragment-major (wb_off), so the 16 bytes a lane needs for one 16x32 MFMA
+// "A" fragment are contiguous and a wave fetches a fragment with ONE coalesced 1 KB load straight into registers, one stage
+// ahead (L2 resident: every workgroup reads the same slice).  Only the activation tile (16.6 KB per stage, two LDS buffers,
+// one barrier per stage) goes through LDS; its loads run two stages ahead (they come from HBM / MALL).
+// 512 threads: the 64-deep stage is split in K between two groups of four waves, each wave owning 32 channels x 128 tokens,
+// so no two waves fetch the same weight fragment, every SIMD holds two waves, and LDS fragment traffic is what a 64x64 wave
+// tile would read.  The two K halves are summed through LDS at the end and each group finishes half of the tokens.
+// ------------------------------------------------------------------------------------------------
+constexpr int DK_MAX_B = 1024;    // batch rows the deep-K kernel can number live tiles for (larger batches: identity map)
+
+template <int TAPS, bool XH>
+__global__ __launch_bounds__(512) void conv_dk_kernel(const ConvGemmArgs a) {
+  constexpr int PAD = (TAPS - 1) / 2;
+  constexpr int TOK = 128;
+  constexpr int XROWS = TOK + TAPS - 1;
+  constexpr int XU = XH ? 8 : 16;                   // 16-byte global units per activation row per stage
+  constexpr int XE = XH ? 8 : 4;
+  constexpr int X_IT = (XROWS * XU + 511) / 512;
+  constexpr int XBUF = XROWS * 128;
+  constexpr int NW = TAPS * 2;                      // weight fragments per wave per stage
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tiles_n = (a.N + TOK - 1) / TOK;
+  const int co0 = blockIdx.y * TILE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // scalar: everything per-wave below stays in SGPRs
+  const int kg = wave >> 2, wq = wave & 3;          // waves w and w+4 share a SIMD: one of each K group
+  const int r = lane & 15, g = lane >> 4;
+  const __bf16* Wp = reinterpret_cast<const __bf16*>(a.Wp);
+
+  // Workgroup -> token tile.  A workgroup fills a CU (registers), so a launch with about as many live tiles as CUs must not
+  // lose a CU to a padding tile: with tile skipping on, the live tiles of the batch are numbered first (workgroups go to the
+  // XCDs round-robin, so consecutive ids spread evenly) and the workgroups after them zero-fill the padding tiles.
+  __shared__ int pre_s[DK_MAX_B + 1];               // exclusive prefix of live tiles per batch row, [B] = total
+  int b, n0;
+  bool live = true;
+  if (a.skip_halo >= 0 && a.B <= DK_MAX_B) {
+    if (wave == 0) {
+      int run = 0;
+      for (int base = 0; base < a.B; base += 64) {
+        const int i = base + lane;
+        const int cnt = i < a.B ? min(tiles_n, max(0, (min(a.lens[i] + a.skip_halo, a.N) + TOK - 1) / TOK)) : 0;
+        int inc = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off, 64); if (lane >= off) inc += v; }
+        if (i < a.B) pre_s[i] = run + inc - cnt;
+        run += __shfl(inc, 63, 64);
+      }
+      if (lane == 0) pre_s[a.B] = run;
+    }
+    __syncthreads();
+    const int nlive = pre_s[a.B];
+    int w = blockIdx.x, lo = 0, hi = a.B;             // largest row lo with key(lo) <= w, key = live (dead) tiles before the row
+    live = w < nlive;
+    if (!live) w -= nlive;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      const int key = live ? pre_s[mid] : mid * tiles_n - pre_s[mid];
+      if (key <= w) lo = mid; else hi = mid;
+    }
+    b = lo;
+    const int live_b = pre_s[b + 1] - pre_s[b];
+    n0 = (live ? w - pre_s[b] : live_b + (w - (b * tiles_n - pre_s[b]))) * TOK;
+  } else {
+    b = blockIdx.x / tiles_n;
+    n0 = (blockIdx.x - b * tiles_n) * TOK;
+    if (a.skip_halo >= 0) live = n0 < a.lens[b] + a.skip_halo;
+  }
+
+  if (!live) {                                        // padding beyond the halo: keep the output defined
+    if (!a.accumulate) {
+      for (int u = tid; u < TOK * 32; u += 512) {
+        const int row = u >> 5, q = u & 31;
+        const int n = n0 + row, co = co0 + q * 4;
+        if (n < a.N && co < a.Cout) {
+          if (a.y_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.Y) + ((size_t)b * a.N + n) * a.ldy + co) = make_uint2(0u, 0u);
+          else {
+            float* dst = a.Y + ((size_t)b * a.N + n) * a.ldy + co;
+            if (co + 3 < a.Cout) *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+            else for (int e = 0; co + e < a.Cout; ++e) dst[e] = 0.f;
+          }
+        }
+      }
+    }
+    return;
+  }
+
+  const int nchunks = a.CinP / 64;
+  // Every staging access is unconditional (addresses are clamped, zeros are selected in when the value is stored): loads
+  // inside divergent branches make the compiler give up counting vmcnt and drain the whole prefetch queue at each use.
+  size_t xoff[X_IT]; int xlds[X_IT], xci[X_IT];                     // xci < 0: row outside the batch row (conv zero padding)
+#pragma unroll
+  for (int it = 0; it < X_IT; ++it) {
+    const int u = min(tid + it * 512, XROWS * XU - 1);              // surplus slots repeat the last unit (same value, same place)
+    const int row = u / XU, q = u % XU;
+    const int n = n0 + row - PAD;
+    const bool ok = n >= 0 && n < a.N;
+    xoff[it] = ok ? ((size_t)b * a.N + n) * a.ldx + q * XE : 0;
+    xci[it] = ok ? q * XE : -1;
+    xlds[it] = XH ? lds_off(row, q) : lds_off(row, q >> 1) + ((q & 1) << 3);
+  }
+  // fragment (tap, i) of stage ch: element offset wbase + ((tap * (CoutP/16) + i) * (CinP/32) + 2 * ch) * 512
+  const __bf16* const wwave = Wp + ((size_t)((co0 >> 4) + wq * 2) * (a.CinP >> 5) + kg) * 512;      // wave-uniform
+  const size_t wtap = (size_t)(a.CoutP >> 4) * (a.CinP >> 5) * 512, wrow = (size_t)(a.CinP >> 5) * 512;
+  const int wlane = lane * 8;
+  f32x4 wa[NW], wb[NW], xa[X_IT], xb[XH ? X_IT : 1];
+  // chunk indices past the end re-read the last chunk (never consumed)
+#define DK_LOAD_W(CH, WR)                                                                                            \
+  {                                                                                                                  \
+    const __bf16* wp_ = wwave + (size_t)min((CH), nchunks - 1) * 1024;                                               \
+    _Pragma("unroll") for (int tap = 0; tap < TAPS; ++tap) {                                                         \
+      WR[tap * 2] = *reinterpret_cast<const f32x4*>(wp_ + tap * wtap + wlane);                                       \
+      WR[tap * 2 + 1] = *reinterpret_cast<const f32x4*>(wp_ + tap * wtap + wrow + wlane);                            \
+    }                                                                                                                \
+  }
+#define DK_LOAD_X(CH, XR)                                                                                            \
+  {                                                                                                                  \
+    const int ch_ = min((CH), nchunks - 1) * 64;                                                                     \
+    _Pragma("unroll") for (int it = 0; it < X_IT; ++it) {                                                            \
+      const size_t off_ = (xci[it] >= 0 && ch_ + xci[it] < a.Cin) ? xoff[it] + ch_ : 0;                              \
+      if constexpr (XH) XR[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.X) + off_);       \
+      else XR[it] = *reinterpret_cast<const f32x4*>(a.X + off_);                                                     \
+    }                                                                                                                \
+  }
+#define DK_STORE_X(CH, BASE, XR)                                                                                     \
+  {                                                                                                                  \
+    const int ch_ = min((CH), nchunks - 1) * 64;                                                                     \
+    _Pragma("unroll") for (int it = 0; it < X_IT; ++it) {                                                            \
+      const f32x4 v_ = (xci[it] >= 0 && ch_ + xci[it] < a.Cin) ? XR[it] : f32x4{0.f, 0.f, 0.f, 0.f};                 \
+      if constexpr (XH) *reinterpret_cast<f32x4*>((BASE) + xlds[it]) = v_;                                           \
+      else *reinterpret_cast<uint2*>((BASE) + xlds[it]) = pack_bf16x4v(v_);                                          \
+    }                                                                                                                \
+  }
+  // accumulators as sixteen named vectors (c<i><j>: 16-channel sub-tile i, 16-token sub-tile j) and the matrix block written
+  // out per tap: no indexed arrays, so every copy of the block keeps its state in VGPRs
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 c00 = zero4, c01 = zero4, c02 = zero4, c03 = zero4, c04 = zero4, c05 = zero4, c06 = zero4, c07 = zero4;
+  f32x4 c10 = zero4, c11 = zero4, c12 = zero4, c13 = zero4, c14 = zero4, c15 = zero4, c16 = zero4, c17 = zero4;
+  const int xfrag0 = lds_off(r, kg * 4 + g);                        // + j * 16 * 128
+  const int xfrag1 = lds_off(r + 1, kg * 4 + g);
+  const int xfrag2 = lds_off(r + 2, kg * 4 + g);
+#define DK_FRAG(P) (*reinterpret_cast<const float4*>(P))
+#define DK_MMA(W, X, C) C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W), __builtin_bit_cast(bf16x8, X), C, 0, 0, 0);
+#define DK_TAP(BASE, W0, W1, XF)                                                                                     \
+  {                                                                                                                  \
+    const unsigned char* xp_ = (BASE) + (XF);                                                                        \
+    const float4 x0 = DK_FRAG(xp_), x1 = DK_FRAG(xp_ + 2048), x2 = DK_FRAG(xp_ + 4096), x3 = DK_FRAG(xp_ + 6144);    \
+    const float4 x4 = DK_FRAG(xp_ + 8192), x5 = DK_FRAG(xp_ + 10240), x6 = DK_FRAG(xp_ + 12288), x7 = DK_FRAG(xp_ + 14336); \
+    DK_MMA(W0, x0, c00) DK_MMA(W0, x1, c01) DK_MMA(W0, x2, c02) DK_MMA(W0, x3, c03)                                   \
+    DK_MMA(W0, x4, c04) DK_MMA(W0, x5, c05) DK_MMA(W0, x6, c06) DK_MMA(W0, x7, c07)                                   \
+    DK_MMA(W1, x0, c10) DK_MMA(W1, x1, c11) DK_MMA(W1, x2, c12) DK_MMA(W1, x3, c13)                                   \
+    DK_MMA(W1, x4, c14) DK_MMA(W1, x5, c15) DK_MMA(W1, x6, c16) DK_MMA(W1, x7, c17)                                   \
+  }
+  // this wave's half (kg) of the stage's K range, all taps
+#define DK_MFMA(BASE, WR)                                                                                            \
+  {                                                                                                                  \
+    DK_TAP(BASE, WR[0], WR[1], xfrag0)                                                                               \
+    if constexpr (TAPS == 3) { DK_TAP(BASE, WR[2], WR[3], xfrag1) DK_TAP(BASE, WR[4], WR[5], xfrag2) }               \
+  }
+  // stage C: activations of chunk C+1 (in XS) move to buffer NXT and chunk C+3 is requested (IN); the matrix block reads
+  // buffer CUR with the weights of chunk C (in WR), after which WR is refilled with chunk C+2 (MM).
+  // Stamps (s_memtime, one workgroup): 2.8 k cycles per stage = 1.75 k with both waves of a SIMD in their matrix block
+  // (96 MFMAs, 18 cycles each) + 0.45 k storing / 0.26 k requesting activations + 0.17 k requesting weights + the barrier;
+  // prologue 3.3 k, K-half exchange 1.3 k, output stores 6.3 k.  Tried and measured equal within 1 % on the full step:
+  // running group 0 as IN,MM and group 1 as MM,IN (a lone wave's matrix block then takes 2.2 k: its fragment reads are no
+  // longer hidden by the partner), and an LDS-staged coalesced epilogue (a CU retires a 64 KB fp32 tile at ~16 B/clk either way).
+#define DK_IN(C, NXT, XS)                                                                                            \
+  {                                                                                                                  \
+    if constexpr (XH) { DK_STORE_X((C) + 1, NXT, XS) DK_LOAD_X((C) + 3, XS) }                                        \
+    else { DK_STORE_X((C) + 1, NXT, xa) DK_LOAD_X((C) + 2, xa) }    /* fp32 rows: one register set, one stage ahead */ \
+  }
+#define DK_MM(C, CUR, WR)                                                                                            \
+  {                                                                                                                  \
+    DK_MFMA(CUR, WR)                                                                                                 \
+    DK_LOAD_W((C) + 2, WR)                                                                                           \
+  }
+  unsigned char* const buf0 = smem;
+  unsigned char* const buf1 = smem + XBUF;
+  DK_LOAD_X(0, xa)
+  DK_LOAD_W(0, wa)
+  DK_STORE_X(0, buf0, xa)
+  // issue order = the order the loop leaves behind, pinned so that the vmcnt counts merged at the loop header are the
+  // steady-state ones
+  if constexpr (XH) {
+    DK_LOAD_X(1, xb)
+    __builtin_amdgcn_sched_barrier(0);
+    DK_LOAD_X(2, xa)
+  } else {
+    DK_LOAD_X(1, xa)
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  DK_LOAD_W(1, wb)
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+  // stages go in unconditional pairs plus a tail: a skippable second half would put a path into the loop on which the
+  // youngest loads are different ones, and every wait would be sized for that path
+  for (int c = 0; c + 1 < nchunks; c += 2) {
+    DK_IN(c, buf1, xb) DK_MM(c, buf0, wa)
+    __syncthreads();
+    DK_IN(c + 1, buf0, xa) DK_MM(c + 1, buf1, wb)
+    __syncthreads();
+  }
+  if (nchunks & 1) {                                                  // odd stage count: the last chunk sits in buffer 0 / wa
+    DK_MFMA(buf0, wa)
+    __syncthreads();
+  }
+#undef DK_LOAD_W
+#undef DK_LOAD_X
+#undef DK_STORE_X
+#undef DK_MFMA
+#undef DK_TAP
+#undef DK_MMA
+#undef DK_FRAG
+#undef DK_IN
+#undef DK_MM
+
+  // sum the two K halves: each wave hands the token half it does not finish to its partner (wave ^ 4) through LDS.
+  // The loop's last barrier has retired every fragment read, so the activation buffers are free.
+  unsigned char* const ex = smem + (size_t)(wq * 2) * 8 * 1024;
+#define DK_GIVE(SLOT, LO, HI) *reinterpret_cast<f32x4*>(ex + (kg * 8 + (SLOT)) * 1024 + lane * 16) = kg == 0 ? (HI) : (LO);
+  DK_GIVE(0, c00, c04) DK_GIVE(1, c01, c05) DK_GIVE(2, c02, c06) DK_GIVE(3, c03, c07)
+  DK_GIVE(4, c10, c14) DK_GIVE(5, c11, c15) DK_GIVE(6, c12, c16) DK_GIVE(7, c13, c17)
+#undef DK_GIVE
+  __syncthreads();
+  f32x4 res[2][4];
+#define DK_TAKE(I, JJ, LO, HI) res[I][JJ] = (kg == 0 ? (LO) : (HI)) + *reinterpret_cast<const f32x4*>(ex + ((1 - kg) * 8 + (I) * 4 + (JJ)) * 1024 + lane * 16);
+  DK_TAKE(0, 0, c00, c04) DK_TAKE(0, 1, c01, c05) DK_TAKE(0, 2, c02, c06) DK_TAKE(0, 3, c03, c07)
+  DK_TAKE(1, 0, c10, c14) DK_TAKE(1, 1, c11, c15) DK_TAKE(1, 2, c12, c16) DK_TAKE(1, 3, c13, c17)
+#undef DK_TAKE
+
+  // epilogue: lane holds channels co..co+3 of token n; this wave finishes token sub-tiles 4*kg .. 4*kg+3 of its 32 channels
+  const int len_b = a.lens ? a.lens[b] : a.N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int co = co0 + wq * 32 + i * 16 + g * 4;
+    if (co >= a.Cout) continue;
+    const bool full = (co + 3 < a.Cout);
+    float bv[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (co + e < a.Cout) {
+        if (a.bias) bv[e] = a.bias[co + e];
+        if (a.post_scale) { sc[e] = a.post_scale[co + e]; sh[e] = a.post_shift[co + e]; }
+      }
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int n = n0 + (kg * 4 + jj) * 16 + r;
+      if (n >= a.N) continue;
+      const size_t row = (size_t)b * a.N + n;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = res[i][jj][e] + bv[e];
+        if (a.relu) t = fmaxf(t, 0.f);
+        t = t * sc[e] + sh[e];
+        v[e] = t * a.out_scale;
+      }
+      if (a.relu_aux) {
+        if (a.aux_bf16) {
+          const bf16x4 av = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.relu_aux) + row * a.ld_aux + co);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (!((float)av[e] > 0.f)) v[e] = 0.f;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < a.Cout && !(a.relu_aux[row * a.ld_aux + co + e] > 0.f)) v[e] = 0.f;
+        }
+      }
+      if (a.mask_rows && n >= len_b) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+      if (a.y_bf16) {
+        *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.Y) + row * a.ldy + co) = pack_bf16x4(make_float4(v[0], v[1], v[2], v[3]));
+        continue;
+      }
+      float* dst = a.Y + row * a.ldy + co;
+      if (full) {
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (a.accumulate) {
+          const float4 old = *reinterpret_cast<const float4*>(dst);
+          o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+        }
+        *reinterpret_cast<float4*>(dst) = o;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (co + e < a.Cout) dst[e] = a.accumulate ? dst[e] + v[e] : v[e];
+      }
+    }
+  }
+}
+
+template <int TAPS, bool XH>
+void launch_conv_dk(const ConvGemmArgs& a, hipStream_t s) {
+  const size_t smem = std::max<size_t>((size_t)2 * (128 + TAPS - 1) * 128, (size_t)128 * 528);
+  static bool configured = false;
+  if (!configured) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dk_kernel<TAPS, XH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    configured = true;
+  }
+  dim3 grid(a.B * dx_cdiv(a.N, 128), a.CoutP / TILE);
+  hipLaunchKernelGGL((conv_dk_kernel<TAPS, XH>), grid, dim3(512), smem, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -817,14 +1147,14 @@ __global__ void pack_weights_kernel(const float* __restrict__ W, T* __restrict__
       const int co = (int)((i / CinP_f) % CoutP_f);
       const int tap = (int)(i / ((size_t)CinP_f * CoutP_f));
       const float v = (co < Cout && ci < Cin) ? W[((size_t)co * Cin + ci) * taps + tap] : 0.f;
-      fwd[i] = (T)v;
+      fwd[sizeof(T) == 2 ? wb_off(tap, co, ci, CoutP_f, CinP_f) : i] = (T)v;
     } else {
       const size_t k = i - nf;
       const int co = (int)(k % CoutP_b);
       const int ci = (int)((k / CoutP_b) % CinP_b);
       const int tap = (int)(k / ((size_t)CoutP_b * CinP_b));
       const float v = (co < Cout && ci < Cin) ? W[((size_t)co * Cin + ci) * taps + (taps - 1 - tap)] : 0.f;
-      bwd[k] = (T)v;
+      bwd[sizeof(T) == 2 ? wb_off(tap, ci, co, CinP_b, CoutP_b) : k] = (T)v;
     }
   }
 }
@@ -846,13 +1176,13 @@ __global__ void pack_weights_batched_kernel(const PackDesc* __restrict__ descs) 
       const int ci = (int)(i % d.CinP_f);
       const int co = (int)((i / d.CinP_f) % d.CoutP_f);
       const int tap = (int)(i / ((size_t)d.CinP_f * d.CoutP_f));
-      fwd[i] = (T)((co < d.Cout && ci < d.Cin) ? d.W[((size_t)co * d.Cin + ci) * d.taps + tap] : 0.f);
+      fwd[sizeof(T) == 2 ? wb_off(tap, co, ci, d.CoutP_f, d.CinP_f) : i] = (T)((co < d.Cout && ci < d.Cin) ? d.W[((size_t)co * d.Cin + ci) * d.taps + tap] : 0.f);
     } else {
       const size_t k = i - nf;
       const int co = (int)(k % d.CoutP_b);
       const int ci = (int)((k / d.CoutP_b) % d.CinP_b);
       const int tap = (int)(k / ((size_t)d.CoutP_b * d.CinP_b));
-      bwd[k] = (T)((co < d.Cout && ci < d.Cin) ? d.W[((size_t)co * d.Cin + ci) * d.taps + (d.taps - 1 - tap)] : 0.f);
+      bwd[sizeof(T) == 2 ? wb_off(tap, ci, co, d.CinP_b, d.CoutP_b) : k] = (T)((co < d.Cout && ci < d.Cin) ? d.W[((size_t)co * d.Cin + ci) * d.taps + (d.taps - 1 - tap)] : 0.f);
     }
   }
 }
@@ -986,7 +1316,12 @@ int dx_conv_gemm(const void* Xv, int ldx, const void* Wp, const float* bias, voi
   hipStream_t s = (hipStream_t)stream;
   dx_prof_begin(DX_PROF_CONV_GEMM, s);
   static const int use_ws = getenv("DX_CONV_WS") ? atoi(getenv("DX_CONV_WS")) : 1;
-  if (bf16 && use_ws && d[1] == 128 && (long)B * dx_cdiv(N, 128) >= 64) {      // short-K layers: weight-stationary persistent kernel
+  static const int use_dk = getenv("DX_CONV_DK") ? atoi(getenv("DX_CONV_DK")) : 1;
+  // deep-K layers: weights straight from the fragment-major pack into registers, live tiles numbered first
+  if (bf16 && use_dk && d[1] >= 256) {
+    if (x_bf16) { if (taps == 3) launch_conv_dk<3, true>(a, s); else launch_conv_dk<1, true>(a, s); }
+    else { if (taps == 3) launch_conv_dk<3, false>(a, s); else launch_conv_dk<1, false>(a, s); }
+  } else if (bf16 && use_ws && d[1] == 128 && (long)B * dx_cdiv(N, 128) >= 64) {      // short-K layers: weight-stationary persistent kernel
     if (x_bf16) { if (taps == 3) launch_conv_ws<3, true>(a, s); else launch_conv_ws<1, true>(a, s); }
     else { if (taps == 3) launch_conv_ws<3, false>(a, s); else launch_conv_ws<1, false>(a, s); }
   } else if (bf16) { if (taps == 3) launch_conv<__bf16, 3>(a, s); else launch_conv<__bf16, 1>(a, s); }
