@@ -167,7 +167,7 @@ def main():
             if os.path.exists(pmc):
                 with open(pmc) as f:
                     traffic = json.load(f).get(args.precision, {}).get('hbm_bytes_per_launch')
-            roofline = {'bound': 'mfma', 'kernel': 'conv_gemm_kernel (Conv1d/Linear as MFMA GEMM, all instantiations)',
+            roofline = {'bound': 'mfma', 'kernel': 'conv-GEMM family: conv_ws_kernel / conv_dk_kernel / conv_gemm_kernel (Conv1d/Linear as MFMA GEMM, forward + input gradient)',
                         'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS[args.precision], 'unit': 'TFLOP/s',
                         'frac': round(achieved / PEAK_TFLOPS[args.precision], 4), 'traffic': traffic,
                         'launches': n.value, 'avg_launch_us': round(1e3 * ms.value / n.value, 2),
@@ -184,7 +184,7 @@ def main():
                                    f'L_max={int(batch[5].max())}, T_max={int(batch[9].max())}, {frames} valid frames/GPU/step; '
                                    'forward + loss (mel L1/L2, adversarial CE, post-mult, energy + pitch consistency) + backward'
                                    + (' + bucketed RCCL gradient all-reduce' if world > 1 else '') + ', dropout on, weights re-packed every step',
-                       'operands': 'bf16 MFMA operands for Conv1d/Linear GEMMs, f32 MFMA attention, fp32 accumulate/activations'
+                       'operands': 'bf16 MFMA operands for Conv1d/Linear GEMMs and attention, fp32 accumulate, 1024-wide hidden tensors and qkv stored bf16'
                                    if args.precision == 'bf16' else 'exact f32 MFMA everywhere',
                        'parallelism': f'dp{world}'},
         }
