@@ -164,26 +164,32 @@ struct UpBwdArgs {
   int B, L, T;
 };
 
-// grid (ceil(T/TT), B), 256 threads.  LDS: g[TT][D+4] (dx_up tile), dw[L][TT], w[L][TT], inner[TT]
+// grid (ceil(T/TT), B), 256 threads.  LDS: g[TT][D+4] (dx_up tile), dw[L][TT], w[L][TT], inner[TT], xs[32][D]
 template <int TT>
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const UpBwdArgs a) {
   constexpr int GLD = D + 4;
+  constexpr int XB = 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* gt = smem;                                   // [TT][GLD]
   float* dwt = gt + TT * GLD;                         // [L][TT]
   float* wt = dwt + (size_t)a.L * TT;                 // [L][TT]
   float* inner = wt + (size_t)a.L * TT;               // [256] scratch
+  float* xst = inner + 256;                           // [XB][D] symbol rows of the current block
   const int b = blockIdx.y, t0 = blockIdx.x * TT;
   const int tid = threadIdx.x;
   const int len = a.lens[b];
   const float* xb = a.xs + (size_t)b * a.L * D;
   // stage dx_up tile (zero beyond T) and the weight tile
+  bool nonzero = false;
   for (int u = tid; u < TT * (D / 4); u += 256) {
     const int tt = u / (D / 4), q = u % (D / 4);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (t0 + tt < a.T) v = *reinterpret_cast<const float4*>(a.dxup + ((size_t)b * a.T + t0 + tt) * D + q * 4);
+    nonzero |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
     *reinterpret_cast<float4*>(gt + tt * GLD + q * 4) = v;
   }
+  // frame tiles beyond the utterance carry an all-zero gradient (the decoder masks them): every term below is then zero
+  if (!__syncthreads_or(nonzero)) return;
   for (int u = tid; u < a.L * TT; u += 256) {
     const int l = u / TT, tt = u % TT;
     wt[u] = (l < len && t0 + tt < a.T) ? a.weights[((size_t)b * a.L + l) * a.T + t0 + tt] : 0.f;
@@ -191,20 +197,32 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const UpBwdArgs a) {
   __syncthreads();
   constexpr int LG = 256 / TT;
   const int tt = tid % TT, lg = tid / TT;
-  // dw[l][t] = sum_c dxup[t][c] * xs[l][c]
+  // dw[l][t] = sum_c dxup[t][c] * xs[l][c].  The symbol rows go through LDS 32 at a time: read straight from global inside the
+  // dot product they were a dependent load per 8 FMAs on a CU that holds one workgroup (LDS), i.e. one wave per SIMD.
   float inn = 0.f;
-  for (int l = lg; l < len; l += LG) {
-    const float* xr = xb + (size_t)l * D;
-    const float* gr = gt + tt * GLD;
-    float s = 0.f;
-#pragma unroll 8
-    for (int c = 0; c < D; c += 4) {
-      const float4 xv = *reinterpret_cast<const float4*>(xr + c);
-      const float4 gv = *reinterpret_cast<const float4*>(gr + c);
-      s += xv.x * gv.x + xv.y * gv.y + xv.z * gv.z + xv.w * gv.w;
+  for (int l0 = 0; l0 < len; l0 += XB) {
+    __syncthreads();
+    for (int u = tid; u < XB * (D / 4); u += 256) {
+      const int l = u / (D / 4), q = u % (D / 4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (l0 + l < len) v = *reinterpret_cast<const float4*>(xb + (size_t)(l0 + l) * D + q * 4);
+      *reinterpret_cast<float4*>(xst + l * D + q * 4) = v;
     }
-    dwt[(size_t)l * TT + tt] = s;
-    inn += s * wt[(size_t)l * TT + tt];
+    __syncthreads();
+    const int lend = min(XB, len - l0);
+    for (int l = lg; l < lend; l += LG) {
+      const float* xr = xst + l * D;                  // one row per wave-iteration: LDS broadcast
+      const float* gr = gt + tt * GLD;
+      float s = 0.f;
+#pragma unroll 8
+      for (int c = 0; c < D; c += 4) {
+        const float4 xv = *reinterpret_cast<const float4*>(xr + c);
+        const float4 gv = *reinterpret_cast<const float4*>(gr + c);
+        s = fmaf(xv.w, gv.w, fmaf(xv.z, gv.z, fmaf(xv.y, gv.y, fmaf(xv.x, gv.x, s))));
+      }
+      dwt[(size_t)(l0 + l) * TT + tt] = s;
+      inn += s * wt[(size_t)(l0 + l) * TT + tt];
+    }
   }
   inner[lg * TT + tt] = inn;
   __syncthreads();
@@ -233,15 +251,24 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const UpBwdArgs a) {
       if (lane == 0 && s != 0.f) atomicAdd(&a.dsigma[(size_t)b * a.L + l], s);
     }
   }
-  // dxs[l][c] += sum_t w[l][t] * dxup[t][c]; thread = channel x half of the symbols
+  // dxs[l][c] += sum_t w[l][t] * dxup[t][c]; thread = channel x half of the symbols, four symbols at a time so that one
+  // g value feeds four FMAs and the weights are read as float4 (0.5 LDS reads per FMA instead of 2)
   {
     const int c = tid & 127, lh = tid >> 7;
-    for (int l = lh; l < len; l += 2) {
-      const float* wrow = wt + (size_t)l * TT;
-      float s = 0.f;
-#pragma unroll 8
-      for (int k = 0; k < TT; ++k) s += wrow[k] * gt[k * GLD + c];
-      if (s != 0.f) atomicAdd(&a.dxs[((size_t)b * a.L + l) * D + c], s);
+    for (int l = lh * 4; l < len; l += 8) {
+      float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int k = 0; k < TT; k += 4) {
+        const float g0 = gt[k * GLD + c], g1 = gt[(k + 1) * GLD + c], g2 = gt[(k + 2) * GLD + c], g3 = gt[(k + 3) * GLD + c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 w4 = *reinterpret_cast<const float4*>(wt + (size_t)min(l + j, a.L - 1) * TT + k);   // rows >= len hold zeros
+          s[j] = fmaf(w4.w, g3, fmaf(w4.z, g2, fmaf(w4.y, g1, fmaf(w4.x, g0, s[j]))));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (l + j < len && s[j] != 0.f) atomicAdd(&a.dxs[((size_t)b * a.L + l + j) * D + c], s[j]);
     }
   }
 }
@@ -303,7 +330,7 @@ __global__ __launch_bounds__(256) void upsample_sym_bwd_kernel(const SymBwdArgs 
 }
 
 template <int TT> size_t fwd_smem(int L) { return ((size_t)L * TT + (size_t)(256 / TT) * TT) * sizeof(float); }
-template <int TT> size_t bwd_smem(int L) { return ((size_t)TT * (D + 4) + 2 * (size_t)L * TT + 256) * sizeof(float); }
+template <int TT> size_t bwd_smem(int L) { return ((size_t)TT * (D + 4) + 2 * (size_t)L * TT + 256 + 32 * D) * sizeof(float); }
 
 template <int TT>
 int launch_fwd(const UpArgs& a, hipStream_t s) {
