@@ -34,7 +34,9 @@ int dx_prof_collect(int kind, int* launches, double* total_ms);
 /* dims[4] = {CoutP_fwd, CinP_fwd, CinP_bwd, CoutP_bwd}: padded sizes of the packed weights (element counts
  * taps*dims[0]*dims[1] and taps*dims[2]*dims[3]); bf16 = 0 packs f32 (exact MFMA), 1 packs bf16 */
 int dx_pack_dims(int Cout, int Cin, int bf16, int* dims);
-/* W: checkpoint layout (Cout, Cin, taps) fp32 -> fwd pack [taps][CoutP][CinP], bwd pack (input-gradient conv) or NULL */
+/* W: checkpoint layout (Cout, Cin, taps) fp32 -> fwd pack, bwd pack (input-gradient conv: channels transposed, taps flipped) or NULL.
+ * The packs are opaque operands of dx_conv_gemm at the same precision: f32 packs are [taps][CoutP][CinP]; bf16 packs hold the
+ * same zero-padded matrices fragment-major (16-row x 32-k blocks in v_mfma_f32_16x16x32_bf16 A-operand order). */
 int dx_pack_weights(const float* W, void* fwd, void* bwd, int Cout, int Cin, int taps, int bf16, void* stream);
 /* every layer of a model in one launch; descs = device array of n 56-byte records
  * {const float* W; void* fwd; void* bwd; int32 Cout, Cin, taps, CoutP_f, CinP_f, CinP_b, CoutP_b, pad} */
