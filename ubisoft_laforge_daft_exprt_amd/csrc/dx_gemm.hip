@@ -664,32 +664,29 @@ __global__ __launch_bounds__(512) void conv_dk_kernel(const ConvGemmArgs a) {
   const int wlane = lane * 8;
   f32x4 wa[NW], wb[NW], xa[X_IT], xb[XH ? X_IT : 1];
   // chunk indices past the end re-read the last chunk (never consumed)
-#define DK_LOAD_W(CH, WR)                                                                                            \
+#define DK_LOAD_W2(TAP, CH, WR)                                                                                      \
   {                                                                                                                  \
-    const __bf16* wp_ = wwave + (size_t)min((CH), nchunks - 1) * 1024;                                               \
-    _Pragma("unroll") for (int tap = 0; tap < TAPS; ++tap) {                                                         \
-      WR[tap * 2] = *reinterpret_cast<const f32x4*>(wp_ + tap * wtap + wlane);                                       \
-      WR[tap * 2 + 1] = *reinterpret_cast<const f32x4*>(wp_ + tap * wtap + wrow + wlane);                            \
-    }                                                                                                                \
+    const __bf16* wp_ = wwave + (size_t)min((CH), nchunks - 1) * 1024 + (TAP) * wtap;                                \
+    WR[(TAP) * 2] = *reinterpret_cast<const f32x4*>(wp_ + wlane);                                                    \
+    WR[(TAP) * 2 + 1] = *reinterpret_cast<const f32x4*>(wp_ + wrow + wlane);                                         \
   }
-#define DK_LOAD_X(CH, XR)                                                                                            \
-  {                                                                                                                  \
-    const int ch_ = min((CH), nchunks - 1) * 64;                                                                     \
-    _Pragma("unroll") for (int it = 0; it < X_IT; ++it) {                                                            \
-      const size_t off_ = (xci[it] >= 0 && ch_ + xci[it] < a.Cin) ? xoff[it] + ch_ : 0;                              \
-      if constexpr (XH) XR[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.X) + off_);       \
-      else XR[it] = *reinterpret_cast<const f32x4*>(a.X + off_);                                                     \
-    }                                                                                                                \
-  }
-#define DK_STORE_X(CH, BASE, XR)                                                                                     \
+#define DK_LOAD_W(CH, WR) { _Pragma("unroll") for (int tap = 0; tap < TAPS; ++tap) DK_LOAD_W2(tap, CH, WR) }
+#define DK_LOAD_X1(IT, CH, XR)                                                                                       \
   {                                                                                                                  \
     const int ch_ = min((CH), nchunks - 1) * 64;                                                                     \
-    _Pragma("unroll") for (int it = 0; it < X_IT; ++it) {                                                            \
-      const f32x4 v_ = (xci[it] >= 0 && ch_ + xci[it] < a.Cin) ? XR[it] : f32x4{0.f, 0.f, 0.f, 0.f};                 \
-      if constexpr (XH) *reinterpret_cast<f32x4*>((BASE) + xlds[it]) = v_;                                           \
-      else *reinterpret_cast<uint2*>((BASE) + xlds[it]) = pack_bf16x4v(v_);                                          \
-    }                                                                                                                \
+    const size_t off_ = (xci[IT] >= 0 && ch_ + xci[IT] < a.Cin) ? xoff[IT] + ch_ : 0;                                \
+    if constexpr (XH) XR[IT] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.X) + off_);         \
+    else XR[IT] = *reinterpret_cast<const f32x4*>(a.X + off_);                                                       \
   }
+#define DK_LOAD_X(CH, XR) { _Pragma("unroll") for (int it = 0; it < X_IT; ++it) DK_LOAD_X1(it, CH, XR) }
+#define DK_STORE_X1(IT, CH, BASE, XR)                                                                                \
+  {                                                                                                                  \
+    const int ch_ = min((CH), nchunks - 1) * 64;                                                                     \
+    const f32x4 v_ = (xci[IT] >= 0 && ch_ + xci[IT] < a.Cin) ? XR[IT] : f32x4{0.f, 0.f, 0.f, 0.f};                   \
+    if constexpr (XH) *reinterpret_cast<f32x4*>((BASE) + xlds[IT]) = v_;                                             \
+    else *reinterpret_cast<uint2*>((BASE) + xlds[IT]) = pack_bf16x4v(v_);                                            \
+  }
+#define DK_STORE_X(CH, BASE, XR) { _Pragma("unroll") for (int it = 0; it < X_IT; ++it) DK_STORE_X1(it, CH, BASE, XR) }
   // accumulators as sixteen named vectors (c<i><j>: 16-channel sub-tile i, 16-token sub-tile j) and the matrix block written
   // out per tap: no indexed arrays, so every copy of the block keeps its state in VGPRs
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -700,46 +697,87 @@ __global__ __launch_bounds__(512) void conv_dk_kernel(const ConvGemmArgs a) {
   const int xfrag2 = lds_off(r + 2, kg * 4 + g);
 #define DK_FRAG(P) (*reinterpret_cast<const float4*>(P))
 #define DK_MMA(W, X, C) C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W), __builtin_bit_cast(bf16x8, X), C, 0, 0, 0);
-#define DK_TAP(BASE, W0, W1, XF)                                                                                     \
+  // One stage of the K loop.  Stamps of the plain order (stage activations, request loads, 48 MFMAs per wave, barrier) gave
+  // 2.8 k cycles per stage: 1.75 k with both waves of a SIMD in their MFMAs (18 cycles each) and 1.05 k with both of them
+  // stuck ISSUING memory instructions (the CU's address path takes a 1 KB wave-load per 16 cycles: 72 loads = 1.15 k cycles
+  // per stage) while the matrix pipe idles.  A wave issues in order, so the only way to overlap the two is inside the wave:
+  // the stage is cut into half-taps of 8 MFMAs (128 cycles of matrix pipe) and its memory work is spread between them -
+  // fragment reads one half-tap ahead (two register sets), the LDS store + global request of one activation unit, or the
+  // refill of one tap's weight registers (free once that tap's MFMAs have issued), per gap.  sched_barriers pin the order.
+  float4 p0, p1, p2, p3, q0, q1, q2, q3;
+#define DK_RD4(P, X0, X1, X2, X3) { const unsigned char* xp_ = (P); X0 = DK_FRAG(xp_); X1 = DK_FRAG(xp_ + 2048); X2 = DK_FRAG(xp_ + 4096); X3 = DK_FRAG(xp_ + 6144); }
+#define DK_MM8(W0, W1, X0, X1, X2, X3, A0, A1, A2, A3, B0, B1, B2, B3)                                               \
   {                                                                                                                  \
-    const unsigned char* xp_ = (BASE) + (XF);                                                                        \
-    const float4 x0 = DK_FRAG(xp_), x1 = DK_FRAG(xp_ + 2048), x2 = DK_FRAG(xp_ + 4096), x3 = DK_FRAG(xp_ + 6144);    \
-    const float4 x4 = DK_FRAG(xp_ + 8192), x5 = DK_FRAG(xp_ + 10240), x6 = DK_FRAG(xp_ + 12288), x7 = DK_FRAG(xp_ + 14336); \
-    DK_MMA(W0, x0, c00) DK_MMA(W0, x1, c01) DK_MMA(W0, x2, c02) DK_MMA(W0, x3, c03)                                   \
-    DK_MMA(W0, x4, c04) DK_MMA(W0, x5, c05) DK_MMA(W0, x6, c06) DK_MMA(W0, x7, c07)                                   \
-    DK_MMA(W1, x0, c10) DK_MMA(W1, x1, c11) DK_MMA(W1, x2, c12) DK_MMA(W1, x3, c13)                                   \
-    DK_MMA(W1, x4, c14) DK_MMA(W1, x5, c15) DK_MMA(W1, x6, c16) DK_MMA(W1, x7, c17)                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    DK_MMA(W0, X0, A0) DK_MMA(W0, X1, A1) DK_MMA(W0, X2, A2) DK_MMA(W0, X3, A3)                                       \
+    DK_MMA(W1, X0, B0) DK_MMA(W1, X1, B1) DK_MMA(W1, X2, B2) DK_MMA(W1, X3, B3)                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
   }
-  // this wave's half (kg) of the stage's K range, all taps
-#define DK_MFMA(BASE, WR)                                                                                            \
+#define DK_MM_LO(W0, W1, X0, X1, X2, X3) DK_MM8(W0, W1, X0, X1, X2, X3, c00, c01, c02, c03, c10, c11, c12, c13)
+#define DK_MM_HI(W0, W1, X0, X1, X2, X3) DK_MM8(W0, W1, X0, X1, X2, X3, c04, c05, c06, c07, c14, c15, c16, c17)
+  // activation unit IT of the stage: chunk C+1 (held in XS since two stages ago) -> buffer NXT, then request chunk C+3 into
+  // the same registers (fp32 rows: one register set, one stage ahead)
+#define DK_XSLOT(IT, C, NXT, XS)                                                                                     \
+  if constexpr ((IT) < X_IT) {                                                                                       \
+    if constexpr (XH) { DK_STORE_X1(IT, (C) + 1, NXT, XS) DK_LOAD_X1(IT, (C) + 3, XS) }                              \
+    else { DK_STORE_X1(IT, (C) + 1, NXT, xa) DK_LOAD_X1(IT, (C) + 2, xa) }                                           \
+  }
+  // stage C: this wave's half (kg) of the K range of chunk C from buffer CUR / weight registers WR, all taps
+#define DK_STAGE(C, CUR, NXT, XS, WR)                                                                                \
   {                                                                                                                  \
-    DK_TAP(BASE, WR[0], WR[1], xfrag0)                                                                               \
-    if constexpr (TAPS == 3) { DK_TAP(BASE, WR[2], WR[3], xfrag1) DK_TAP(BASE, WR[4], WR[5], xfrag2) }               \
+    DK_RD4((CUR) + xfrag0, p0, p1, p2, p3)                                                                           \
+    DK_RD4((CUR) + xfrag0 + 8192, q0, q1, q2, q3)                                                                    \
+    DK_MM_LO(WR[0], WR[1], p0, p1, p2, p3)                                                                           \
+    if constexpr (TAPS == 3) {                                                                                       \
+      DK_RD4((CUR) + xfrag1, p0, p1, p2, p3)                                                                         \
+      DK_XSLOT(0, C, NXT, XS) DK_XSLOT(3, C, NXT, XS)                                                                \
+      DK_MM_HI(WR[0], WR[1], q0, q1, q2, q3)                                                                         \
+      DK_RD4((CUR) + xfrag1 + 8192, q0, q1, q2, q3)                                                                  \
+      DK_LOAD_W2(0, (C) + 2, WR)                                                                                     \
+      DK_MM_LO(WR[2], WR[3], p0, p1, p2, p3)                                                                         \
+      DK_RD4((CUR) + xfrag2, p0, p1, p2, p3)                                                                         \
+      DK_XSLOT(1, C, NXT, XS) DK_XSLOT(4, C, NXT, XS)                                                                \
+      DK_MM_HI(WR[2], WR[3], q0, q1, q2, q3)                                                                         \
+      DK_RD4((CUR) + xfrag2 + 8192, q0, q1, q2, q3)                                                                  \
+      DK_LOAD_W2(1, (C) + 2, WR)                                                                                     \
+      DK_MM_LO(WR[4], WR[5], p0, p1, p2, p3)                                                                         \
+      DK_XSLOT(2, C, NXT, XS)                                                                                        \
+      DK_MM_HI(WR[4], WR[5], q0, q1, q2, q3)                                                                         \
+      DK_LOAD_W2(2, (C) + 2, WR)                                                                                     \
+    } else {                                                                                                         \
+      DK_XSLOT(0, C, NXT, XS) DK_XSLOT(1, C, NXT, XS)                                                                \
+      DK_MM_HI(WR[0], WR[1], q0, q1, q2, q3)                                                                         \
+      DK_XSLOT(2, C, NXT, XS) DK_XSLOT(3, C, NXT, XS)                                                                \
+      DK_LOAD_W2(0, (C) + 2, WR)                                                                                     \
+    }                                                                                                                \
+    __syncthreads();                                                                                                 \
   }
-  // stage C: activations of chunk C+1 (in XS) move to buffer NXT and chunk C+3 is requested (IN); the matrix block reads
-  // buffer CUR with the weights of chunk C (in WR), after which WR is refilled with chunk C+2 (MM).
-  // Stamps (s_memtime, one workgroup): 2.8 k cycles per stage = 1.75 k with both waves of a SIMD in their matrix block
-  // (96 MFMAs, 18 cycles each) + 0.45 k storing / 0.26 k requesting activations + 0.17 k requesting weights + the barrier;
-  // prologue 3.3 k, K-half exchange 1.3 k, output stores 6.3 k.  Tried and measured equal within 1 % on the full step:
-  // running group 0 as IN,MM and group 1 as MM,IN (a lone wave's matrix block then takes 2.2 k: its fragment reads are no
-  // longer hidden by the partner), and an LDS-staged coalesced epilogue (a CU retires a 64 KB fp32 tile at ~16 B/clk either way).
-#define DK_IN(C, NXT, XS)                                                                                            \
+  // the last chunk of an odd stage count: nothing left to stage
+#define DK_MFMA_ONLY(CUR, WR)                                                                                        \
   {                                                                                                                  \
-    if constexpr (XH) { DK_STORE_X((C) + 1, NXT, XS) DK_LOAD_X((C) + 3, XS) }                                        \
-    else { DK_STORE_X((C) + 1, NXT, xa) DK_LOAD_X((C) + 2, xa) }    /* fp32 rows: one register set, one stage ahead */ \
+    DK_RD4((CUR) + xfrag0, p0, p1, p2, p3)                                                                           \
+    DK_RD4((CUR) + xfrag0 + 8192, q0, q1, q2, q3)                                                                    \
+    DK_MM_LO(WR[0], WR[1], p0, p1, p2, p3)                                                                           \
+    DK_MM_HI(WR[0], WR[1], q0, q1, q2, q3)                                                                           \
+    if constexpr (TAPS == 3) {                                                                                       \
+      DK_RD4((CUR) + xfrag1, p0, p1, p2, p3)                                                                         \
+      DK_RD4((CUR) + xfrag1 + 8192, q0, q1, q2, q3)                                                                  \
+      DK_MM_LO(WR[2], WR[3], p0, p1, p2, p3)                                                                         \
+      DK_MM_HI(WR[2], WR[3], q0, q1, q2, q3)                                                                         \
+      DK_RD4((CUR) + xfrag2, p0, p1, p2, p3)                                                                         \
+      DK_RD4((CUR) + xfrag2 + 8192, q0, q1, q2, q3)                                                                  \
+      DK_MM_LO(WR[4], WR[5], p0, p1, p2, p3)                                                                         \
+      DK_MM_HI(WR[4], WR[5], q0, q1, q2, q3)                                                                         \
+    }                                                                                                                \
   }
-#define DK_MM(C, CUR, WR)                                                                                            \
-  {                                                                                                                  \
-    DK_MFMA(CUR, WR)                                                                                                 \
-    DK_LOAD_W((C) + 2, WR)                                                                                           \
-  }
+  static_assert(X_IT <= 5, "activation units per thread per stage");
   unsigned char* const buf0 = smem;
   unsigned char* const buf1 = smem + XBUF;
   DK_LOAD_X(0, xa)
   DK_LOAD_W(0, wa)
   DK_STORE_X(0, buf0, xa)
-  // issue order = the order the loop leaves behind, pinned so that the vmcnt counts merged at the loop header are the
-  // steady-state ones
+  // issue order = roughly the order the loop leaves behind, pinned so that the vmcnt counts merged at the loop header are
+  // close to the steady-state ones
   if constexpr (XH) {
     DK_LOAD_X(1, xb)
     __builtin_amdgcn_sched_barrier(0);
@@ -754,24 +792,28 @@ __global__ __launch_bounds__(512) void conv_dk_kernel(const ConvGemmArgs a) {
   // stages go in unconditional pairs plus a tail: a skippable second half would put a path into the loop on which the
   // youngest loads are different ones, and every wait would be sized for that path
   for (int c = 0; c + 1 < nchunks; c += 2) {
-    DK_IN(c, buf1, xb) DK_MM(c, buf0, wa)
-    __syncthreads();
-    DK_IN(c + 1, buf0, xa) DK_MM(c + 1, buf1, wb)
-    __syncthreads();
+    DK_STAGE(c, buf0, buf1, xb, wa)
+    DK_STAGE(c + 1, buf1, buf0, xa, wb)
   }
   if (nchunks & 1) {                                                  // odd stage count: the last chunk sits in buffer 0 / wa
-    DK_MFMA(buf0, wa)
+    DK_MFMA_ONLY(buf0, wa)
     __syncthreads();
   }
+#undef DK_LOAD_W2
 #undef DK_LOAD_W
+#undef DK_LOAD_X1
 #undef DK_LOAD_X
+#undef DK_STORE_X1
 #undef DK_STORE_X
-#undef DK_MFMA
-#undef DK_TAP
+#undef DK_RD4
+#undef DK_MM8
+#undef DK_MM_LO
+#undef DK_MM_HI
+#undef DK_XSLOT
+#undef DK_STAGE
+#undef DK_MFMA_ONLY
 #undef DK_MMA
 #undef DK_FRAG
-#undef DK_IN
-#undef DK_MM
 
   // sum the two K halves: each wave hands the token half it does not finish to its partner (wave ^ 4) through LDS.
   // The loop's last barrier has retired every fragment read, so the activation buffers are free.
