@@ -720,6 +720,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwd
       delta_r = (tid < 64 && qn < a.N) ? a.delta[(size_t)bh * a.N + qn] : 0.f;
     }
     f32x4 pd[4], ds[4];
+    // Dropout words: one 64-bit draw covers 4 consecutive keys of a query row.  Here a lane owns ONE key and 16 query rows, and
+    // the four lanes of a quad (keys 4m .. 4m+3) need the same 16 words: each lane draws 4 of them (rows g*4 + its quad index)
+    // and the quad shares them by DPP instead of every lane drawing all 16 (the draws were ~40 % of this kernel's VALU time).
+    uint32_t wlo[4], whi[4];
+    if (a.thresh) {
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+        const uint64_t w = dx_rand64(a.seed, drop_index(bh, a.N, qbase + qt * 16 + g * 4 + (r & 3), krow) >> 2);
+        wlo[qt] = (uint32_t)w; whi[qt] = (uint32_t)(w >> 32);
+      }
+    }
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
       f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -728,13 +739,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwd
         s = DX_MFMA_BF16(row_frag(Qs, qt * 16 + r, ks, g), kf[ks], s);
         dp = DX_MFMA_BF16(row_frag(Gs, qt * 16 + r, ks, g), vf[ks], dp);
       }
+      float keepv[4] = {1.f, 1.f, 1.f, 1.f};
+      if (a.thresh) {
+        const uint32_t lo0 = __builtin_amdgcn_mov_dpp(wlo[qt], 0x00, 0xF, 0xF, true), hi0 = __builtin_amdgcn_mov_dpp(whi[qt], 0x00, 0xF, 0xF, true);
+        const uint32_t lo1 = __builtin_amdgcn_mov_dpp(wlo[qt], 0x55, 0xF, 0xF, true), hi1 = __builtin_amdgcn_mov_dpp(whi[qt], 0x55, 0xF, 0xF, true);
+        const uint32_t lo2 = __builtin_amdgcn_mov_dpp(wlo[qt], 0xAA, 0xF, 0xF, true), hi2 = __builtin_amdgcn_mov_dpp(whi[qt], 0xAA, 0xF, 0xF, true);
+        const uint32_t lo3 = __builtin_amdgcn_mov_dpp(wlo[qt], 0xFF, 0xF, 0xF, true), hi3 = __builtin_amdgcn_mov_dpp(whi[qt], 0xFF, 0xF, 0xF, true);
+        const uint32_t lo[4] = {lo0, lo1, lo2, lo3}, hi[4] = {hi0, hi1, hi2, hi3};
+        const int field = krow & 3;                      // which 16 bits of the word belong to this lane's key
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t half = (field & 2) ? hi[e] : lo[e];
+          const uint32_t bits = (half >> ((field & 1) * 16)) & 0xFFFFu;
+          keepv[e] = bits >= a.thresh ? a.inv_keep : 0.f;
+        }
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int ql = qt * 16 + g * 4 + e, q = qbase + ql;
         const bool live = key_valid && q < len;
         const float p = live ? __expf(s[e] - lse_s[ql]) : 0.f;
-        float keep = 1.f;
-        if (a.thresh) keep = dx_dropout_scale(a.seed, drop_index(bh, a.N, q, krow), a.thresh, a.inv_keep);
+        const float keep = keepv[e];
         pd[qt][e] = p * keep;
         ds[qt][e] = p * (dp[e] * keep - delta_s[ql]) * QSCALE;
       }
