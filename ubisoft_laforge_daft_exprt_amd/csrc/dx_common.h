@@ -60,15 +60,19 @@ __device__ __forceinline__ float dx_wave_max(float v) {
 }
 
 // ---- counter-based dropout RNG -----------------------------------------------------------------
-// splitmix64 of (seed, index): 64 random bits = four 16-bit keep/drop decisions.  The same (seed, index)
-// is evaluated again in the backward kernels, so no mask tensor is stored.
+// Counter-based draw for (seed, index): 64 random bits = four 16-bit keep/drop decisions.  The same (seed, index) is
+// evaluated again in the backward kernels, so no mask tensor is stored.  Built from 32-bit multiplies (murmur3's block mix and
+// finaliser over the two halves, each half folded into the other): the attention kernels are VALU-bound with dropout on, and
+// splitmix64's three 64-bit multiplies cost twice as many 32-bit multiplier passes.  (Keep rate, cross-field, lag-1 and
+// seed/seed+1 correlations of the keep mask checked on 4 M consecutive and on attention-shaped indices: all at noise level.)
 __device__ __forceinline__ uint64_t dx_rand64(uint64_t seed, uint64_t idx) {
-  uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
+  uint32_t a = (uint32_t)idx ^ (uint32_t)seed;
+  uint32_t b = (uint32_t)(idx >> 32) ^ (uint32_t)(seed >> 32);
+  a *= 0xCC9E2D51u; a = (a << 15) | (a >> 17); a *= 0x1B873593u;
+  b = (b ^ a) * 0x85EBCA6Bu; b ^= b >> 13; b *= 0xC2B2AE35u; b ^= b >> 16;
+  a ^= b; a ^= a >> 16; a *= 0x85EBCA6Bu; a ^= a >> 13; a *= 0xC2B2AE35u; a ^= a >> 16;
+  return ((uint64_t)b << 32) | a;
 }
-// keep-scale for element `elem` (linear index in its tensor): 0 or 1/(1-p).  thresh16 = round(p * 65536).
 __device__ __forceinline__ float dx_dropout_scale(uint64_t seed, uint64_t elem, uint32_t thresh16, float inv_keep) {
   uint64_t r = dx_rand64(seed, elem >> 2);
   uint32_t bits = (uint32_t)(r >> (16 * (elem & 3))) & 0xFFFFu;
