@@ -20,6 +20,10 @@ namespace {
 constexpr int HD = 64;       // head dim
 constexpr int TLD = 68;      // LDS row stride (floats) of a [64][64] tile: 16-B aligned rows, column reads conflict free
 constexpr float QSCALE = 0.125f;  // 1/sqrt(64), exact
+// bf16 kernels keep scores in log2 units (v_exp_f32 is 2^x): the S operand is scaled by QSCALE * log2(e) once when it is
+// loaded, and the saved log-sum-exp is base 2 (scratch between the bf16 forward and backward, never user-visible)
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float QSCALE2 = QSCALE * LOG2E;
 
 struct AttnArgs {
   const float* qkv; int ld;        // [B*N][ld]
@@ -462,7 +466,7 @@ __device__ __forceinline__ bf16x8 load_row8(const __bf16* p, float scale) {
   bf16x8 h = *reinterpret_cast<const bf16x8*>(p);
   if (scale != 1.f) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) h[e] = (__bf16)((float)h[e] * scale);   // scale is a power of two: exact
+    for (int e = 0; e < 8; ++e) h[e] = (__bf16)((float)h[e] * scale);
   }
   return h;
 }
@@ -495,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a)
   const int qload = min(qrow, a.N - 1);
   bf16x8 qf[2];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) qf[ks] = load_row8(base + (size_t)qload * a.ld + h * HD + ks * 32 + g * 8, QSCALE);
+  for (int ks = 0; ks < 2; ++ks) qf[ks] = load_row8(base + (size_t)qload * a.ld + h * HD + ks * 32 + g * 8, QSCALE2);
   f32x4 o[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -517,22 +521,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a)
     }
     f32x4 st[4];
     float mx = -INFINITY;
+    const bool tail_tile = kbase + 64 > len;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) acc = DX_MFMA_BF16(row_frag(Ks, kt * 16 + r, ks, g), qf[ks], acc);
+      if (tail_tile) {                                  // only the last key tile of a row can hold padding keys
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (kbase + kt * 16 + g * 4 + e >= len) acc[e] = -INFINITY;
-        mx = fmaxf(mx, acc[e]);
+        for (int e = 0; e < 4; ++e)
+          if (kbase + kt * 16 + g * 4 + e >= len) acc[e] = -INFINITY;
       }
+      mx = fmaxf(fmaxf(mx, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
       st[kt] = acc;
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __expf(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float ls = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a)
       if (a.thresh) dx_dropout_scale4(a.seed, drop_index(bh, a.N, qrow, kbase + kt * 16 + g * 4), a.thresh, a.inv_keep, keep);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float p = __expf(st[kt][e] - m_new);
+        const float p = __builtin_amdgcn_exp2f(st[kt][e] - m_new);
         ls += p;
         st[kt][e] = p * keep[e];
       }
@@ -566,7 +572,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
       *reinterpret_cast<float4*>(out + dt * 16 + g * 4) = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
-    if (g == 0) a.lse[((size_t)b * a.H + h) * a.N + qrow] = valid ? m_run + logf(l_run) : 0.f;
+    if (g == 0) a.lse[((size_t)b * a.H + h) * a.N + qrow] = valid ? m_run + __log2f(l_run) : 0.f;   // base 2 (see QSCALE2)
   }
 }
 
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
   float delta_q = 0.f;
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    qf[ks] = load_row8(base + (size_t)qload * a.ld + h * HD + ks * 32 + g * 8, QSCALE);
+    qf[ks] = load_row8(base + (size_t)qload * a.ld + h * HD + ks * 32 + g * 8, QSCALE2);
     const size_t o = ((size_t)b * a.N + qload) * a.ldc + h * HD + ks * 32 + g * 8;
     const float4 g0 = *reinterpret_cast<const float4*>(a.dctx + o), g1 = *reinterpret_cast<const float4*>(a.dctx + o + 4);
     const float4 c0 = *reinterpret_cast<const float4*>(a.ctx + o), c1 = *reinterpret_cast<const float4*>(a.ctx + o + 4);
@@ -628,6 +634,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
       DX_TILE_LOAD(QT, vreg, base, a.ld, 2 * a.D + h * HD, kbase + 64, a.N)
     }
     f32x4 ds[4];
+    const bool tail_tile = kbase + 64 > len;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -640,9 +647,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
       if (a.thresh) dx_dropout_scale4(a.seed, drop_index(bh, a.N, qrow, kbase + kt * 16 + g * 4), a.thresh, a.inv_keep, keep);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const bool masked = kbase + kt * 16 + g * 4 + e >= len;
-        const float p = masked ? 0.f : __expf(s[e] - lse_q);
-        s[e] = p * (dp[e] * keep[e] - delta_q) * QSCALE;
+        float p = __builtin_amdgcn_exp2f(s[e] - lse_q);
+        if (tail_tile && kbase + kt * 16 + g * 4 + e >= len) p = 0.f;    // only the last key tile can hold padding keys
+        s[e] = p * (dp[e] * keep[e] - delta_q);                           // x QSCALE: applied once to dQ at the end
       }
       ds[kt] = s;
     }
@@ -656,7 +663,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
     }
   }
   if (qrow < a.N) {
-    const float z = qrow < len ? 1.f : 0.f;
+    const float z = qrow < len ? QSCALE : 0.f;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
       store4(out + dt * 16 + g * 4, dq[dt][0] * z, dq[dt][1] * z, dq[dt][2] * z, dq[dt][3] * z);
@@ -693,7 +700,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwd
   bf16x8 kf[2], vf[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    kf[ks] = load_row8(base + (size_t)kload * a.ld + a.D + h * HD + ks * 32 + g * 8, QSCALE);
+    kf[ks] = load_row8(base + (size_t)kload * a.ld + a.D + h * HD + ks * 32 + g * 8, QSCALE2);
     vf[ks] = load_row8(base + (size_t)kload * a.ld + 2 * a.D + h * HD + ks * 32 + g * 8, 1.f);
   }
   f32x4 dk[4], dv[4];
@@ -720,6 +727,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwd
       delta_r = (tid < 64 && qn < a.N) ? a.delta[(size_t)bh * a.N + qn] : 0.f;
     }
     f32x4 pd[4], ds[4];
+    const bool tail_q = qbase + 64 > len;
     // Dropout words: one 64-bit draw covers 4 consecutive keys of a query row.  Here a lane owns ONE key and 16 query rows, and
     // the four lanes of a quad (keys 4m .. 4m+3) need the same 16 words: each lane draws 4 of them (rows g*4 + its quad index)
     // and the quad shares them by DPP instead of every lane drawing all 16 (the draws were ~40 % of this kernel's VALU time).
@@ -757,11 +765,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwd
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int ql = qt * 16 + g * 4 + e, q = qbase + ql;
-        const bool live = key_valid && q < len;
-        const float p = live ? __expf(s[e] - lse_s[ql]) : 0.f;
+        float p = __builtin_amdgcn_exp2f(s[e] - lse_s[ql]);
+        if (!key_valid || (tail_q && q >= len)) p = 0.f;                  // padding key, or padding query in the last query tile
         const float keep = keepv[e];
         pd[qt][e] = p * keep;
-        ds[qt][e] = p * (dp[e] * keep - delta_s[ql]) * QSCALE;
+        ds[qt][e] = p * (dp[e] * keep - delta_s[ql]);                     // x QSCALE: applied once to dK at the end
       }
     }
     const bf16x8 p01 = pack_pair(pd[0], pd[1]), p23 = pack_pair(pd[2], pd[3]);
@@ -779,7 +787,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwd
   if (krow < a.N) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      store4(outk + dt * 16 + g * 4, dk[dt][0], dk[dt][1], dk[dt][2], dk[dt][3]);
+      store4(outk + dt * 16 + g * 4, dk[dt][0] * QSCALE, dk[dt][1] * QSCALE, dk[dt][2] * QSCALE, dk[dt][3] * QSCALE);
       store4(outv + dt * 16 + g * 4, dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
     }
   }
