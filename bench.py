@@ -76,6 +76,7 @@ def main():
     ap.add_argument('--config', default='C2', choices=['C1', 'C2', 'C5'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--no-dropout', action='store_true', help='diagnostic only: the headline metric is measured with dropout on')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -98,6 +99,8 @@ def main():
     pkg.set_precision(args.precision)
     n_speakers = 12 if world > 1 else 2                                  # C3: 11 speakers + 1; C2: single speaker + 1
     hp = pkg.HyperParams(n_speakers=n_speakers)
+    if args.no_dropout:
+        hp = hp.without_dropout()
     model = pkg.DaftExprt(hp).to(dev)
     model.load_state_dict(synthetic_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 1234), strict=True)
     model.train()
@@ -183,7 +186,7 @@ def main():
             'config': {'workload': f'{args.config}: LJ-shaped training step, {cfg["batch_size"]} utterances/GPU, '
                                    f'L_max={int(batch[5].max())}, T_max={int(batch[9].max())}, {frames} valid frames/GPU/step; '
                                    'forward + loss (mel L1/L2, adversarial CE, post-mult, energy + pitch consistency) + backward'
-                                   + (' + bucketed RCCL gradient all-reduce' if world > 1 else '') + ', dropout on, weights re-packed every step',
+                                   + (' + bucketed RCCL gradient all-reduce' if world > 1 else '') + (', dropout OFF (diagnostic)' if args.no_dropout else ', dropout on') + ', weights re-packed every step',
                        'operands': 'bf16 MFMA operands for Conv1d/Linear GEMMs and attention, fp32 accumulate, 1024-wide hidden tensors and qkv stored bf16'
                                    if args.precision == 'bf16' else 'exact f32 MFMA everywhere',
                        'parallelism': f'dp{world}'},
