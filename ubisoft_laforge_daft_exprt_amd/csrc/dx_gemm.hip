@@ -390,6 +390,21 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, i
     t += wgs_per_cotile;
     live = next_tile(t, b, n0);
     if (live) DX_WS_LOAD(b, n0)
+    // ReLU-gradient mask of THIS tile (input gradient of FF conv2: the bf16 hidden tensor): requested before the matrix block so
+    // that the copy-out below does not start with a dependent global load
+    // (k = 3 only: the k = 1 instantiations would lose a wave per SIMD to the 16 extra registers)
+    bf16x8 auxreg[TAPS == 3 ? 4 : 1];
+    const bool aux_pf = TAPS == 3 && a.relu_aux != nullptr && a.aux_bf16 && a.y_bf16;
+    if constexpr (TAPS == 3) if (aux_pf) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int u = tid + it * 512;
+        const int n = cn0 + (u >> 4), co = co0 + (u & 15) * 8;
+        bf16x8 v = bf16x8{};
+        if (n < a.N && co < a.Cout) v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.relu_aux) + ((size_t)cb * a.N + n) * a.ld_aux + co);
+        auxreg[it] = v;
+      }
+    }
 
     f32x4 acc[2][4];
 #pragma unroll
@@ -455,7 +470,9 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, i
           const size_t grow = (size_t)cb * a.N + n;
           if (a.relu_aux) {
             if (a.aux_bf16) {
-              const bf16x8 av = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.relu_aux) + grow * a.ld_aux + co);
+              bf16x8 av;
+              if constexpr (TAPS == 3) av = auxreg[it];
+              else av = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.relu_aux) + grow * a.ld_aux + co);
 #pragma unroll
               for (int e = 0; e < 8; ++e)
                 if (!((float)av[e] > 0.f)) o[e] = (__bf16)0.f;
