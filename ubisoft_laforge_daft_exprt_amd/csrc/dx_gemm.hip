@@ -1084,8 +1084,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBf16Args 
       for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int u = tid; u < 8 * WB_LD; u += 256) Xs[WB_BK * WB_LD + u] = (__bf16)0.f;
 
-  const bool do_bias = a.dbias != nullptr && ci0 == 0 && tid < TILE;
-  float bsum = 0.f;
+  // Fused bias gradient (column sums of the dY tile), done by the workgroups of input-channel tile 0 with ALL their threads
+  // (thread = channel pair x one quarter of the rows, 4-byte LDS reads).  As 128 threads x 64 two-byte reads it made those
+  // workgroups' first two waves ~1.2 k cycles per chunk slower than everyone else: the kernel's tail.  (Spreading the sums
+  // over all sibling workgroups instead was far worse: 100 k atomics on the same 128 addresses.)
+  const bool do_bias = a.dbias != nullptr && ci0 == 0;
+  float bsum0 = 0.f, bsum1 = 0.f;
   f32x4 dreg[D_IT], xreg[X_IT];
 #define DX_WG_LOAD(B_, NC_)                                                                                                   \
   {                                                                                                                           \
@@ -1152,8 +1156,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBf16Args 
     while (c < total && !live()) advance();
     if (c < total) DX_WG_LOAD(b, nc);
     if (do_bias) {
-#pragma unroll 8
-      for (int k = 0; k < WB_BK; ++k) bsum += (float)Ds[k * WB_LD + tid];
+      const __bf16* col = Ds + (tid >> 6) * (WB_BK / 4) * WB_LD + (tid & 63) * 2;
+#pragma unroll
+      for (int k = 0; k < WB_BK / 4; ++k) {
+        const unsigned v = *reinterpret_cast<const unsigned*>(col + k * WB_LD);
+        bsum0 += __builtin_bit_cast(float, v << 16);
+        bsum1 += __builtin_bit_cast(float, v & 0xffff0000u);
+      }
     }
 #pragma unroll
     for (int ks = 0; ks < WB_BK / 32; ++ks) {
@@ -1188,7 +1197,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBf16Args 
           if (co < a.Cout && acc[t][i][j][e] != 0.f) atomicAdd(&a.G[((size_t)t * a.Cout + co) * a.Cin + ci], acc[t][i][j][e]);
         }
       }
-  if (do_bias && co0 + tid < a.Cout && bsum != 0.f) atomicAdd(&a.dbias[co0 + tid], bsum);
+  if (do_bias) {                                         // workgroup-uniform: fold the four row quarters, one atomic per channel
+    float* red = reinterpret_cast<float*>(Ds);           // the chunk loop is over: its last barrier has retired every tile read
+    __syncthreads();
+    red[(tid >> 6) * TILE + (tid & 63) * 2] = bsum0;
+    red[(tid >> 6) * TILE + (tid & 63) * 2 + 1] = bsum1;
+    __syncthreads();
+    if (tid < TILE && co0 + tid < a.Cout) {
+      const float t = (red[tid] + red[TILE + tid]) + (red[2 * TILE + tid] + red[3 * TILE + tid]);
+      if (t != 0.f) atomicAdd(&a.dbias[co0 + tid], t);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
