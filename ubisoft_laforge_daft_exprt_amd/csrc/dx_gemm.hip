@@ -29,6 +29,7 @@
 namespace {
 
 constexpr int TILE = 128;   // channels and tokens per workgroup
+constexpr int DK_MAX_B = 1024;   // batch rows the persistent / deep-K kernels can number live token tiles for (larger batches: plain order)
 
 struct ConvGemmArgs {
   const float* X; int ldx;
@@ -331,9 +332,64 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, i
 
   const int tiles_n = (a.N + TOK - 1) / TOK;
   const int total = a.B * tiles_n;
-  __shared__ int limit_s[512];                              // per-utterance skip limits (a scalar global load per tile is ~1 k cycles)
-  for (int i = tid; i < min(a.B, 512); i += 512) limit_s[i] = a.skip_halo >= 0 ? a.lens[i] + a.skip_halo : 0x7fffffff;
+  // Token tiles this workgroup walks.  With tile skipping on, the batch's LIVE tiles are numbered first (exclusive prefix of
+  // live tiles per batch row in LDS, binary search per tile) and shared round-robin; padding tiles are zero-filled up front.
+  // Walking (b, tile) in plain order with a stride gave some workgroups two live tiles and others none on the Cout = 128 layers
+  // (256 workgroups, ~250 live tiles of 336): the launch took two tile times instead of one.
+  __shared__ int pre_s[DK_MAX_B + 1];
+  // (only when a workgroup gets few tiles: with ~8 tiles each the strided plain order is balanced enough and skips the search)
+  const bool compact = a.skip_halo >= 0 && a.B <= DK_MAX_B && total <= 4 * wgs_per_cotile;
+  if (compact && wave == 0) {
+    int run = 0;
+    for (int base = 0; base < a.B; base += 64) {
+      const int i = base + lane;
+      const int cnt = i < a.B ? min(tiles_n, max(0, (min(a.lens[i] + a.skip_halo, a.N) + TOK - 1) / TOK)) : 0;
+      int inc = cnt;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off, 64); if (lane >= off) inc += v; }
+      if (i < a.B) pre_s[i] = run + inc - cnt;
+      run += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) pre_s[a.B] = run;
+  }
+  // plain order: the same array holds the per-row skip limits (a scalar global load per tile costs ~1 k cycles)
+  const bool limits_in_lds = !compact && a.skip_halo >= 0 && a.B <= DK_MAX_B;
+  if (limits_in_lds) for (int i = tid; i < a.B; i += 512) pre_s[i] = a.lens[i] + a.skip_halo;
   __syncthreads();
+  const int nlive = compact ? pre_s[a.B] : total;
+  // idx-th live (or padding) tile -> (b, n0)
+  auto locate = [&](int idx, bool want_live, int& b, int& n0) {
+    int lo = 0, hi = a.B;                                   // largest row lo with key(lo) <= idx
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      const int key = want_live ? pre_s[mid] : mid * tiles_n - pre_s[mid];
+      if (key <= idx) lo = mid; else hi = mid;
+    }
+    b = lo;
+    const int live_b = pre_s[b + 1] - pre_s[b];
+    n0 = (want_live ? idx - pre_s[b] : live_b + (idx - (b * tiles_n - pre_s[b]))) * TOK;
+  };
+  auto zero_tile = [&](int b, int n0) {
+    for (int u = tid; u < TOK * 32; u += 512) {
+      const int row = u >> 5, q = u & 31;
+      const int n = n0 + row, co = co0 + q * 4;
+      if (n < a.N && co < a.Cout) {
+        if (a.y_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.Y) + ((size_t)b * a.N + n) * a.ldy + co) = make_uint2(0u, 0u);
+        else {
+          float* dst = a.Y + ((size_t)b * a.N + n) * a.ldy + co;
+          if (co + 3 < a.Cout) *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
+          else for (int e = 0; co + e < a.Cout; ++e) dst[e] = 0.f;
+        }
+      }
+    }
+  };
+  if (compact && !a.accumulate) {
+    for (int d = blockIdx.x; d < total - nlive; d += wgs_per_cotile) {
+      int zb, zn0;
+      locate(d, false, zb, zn0);
+      zero_tile(zb, zn0);
+    }
+  }
   f32x4 xreg[X_IT];
 #define DX_WS_LOAD(B_, N0_)                                                                                          \
   _Pragma("unroll") for (int it = 0; it < X_IT; ++it) {                                                              \
@@ -347,26 +403,34 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, i
     }                                                                                                                \
     xreg[it] = v;                                                                                                    \
   }
-  // next live tile of this workgroup (padding tiles beyond the halo are zero-filled on the way)
+  // this workgroup's first WS_LIST live tiles are located up front, one per thread (a binary search per tile inside the loop sat
+  // on the path to the next tile's prefetch)
+  constexpr int WS_LIST = 128;
+  __shared__ int mine_s[WS_LIST];                          // (b << 16) | tile index
+  if (compact && tid < WS_LIST) {
+    const int idx = blockIdx.x + tid * wgs_per_cotile;
+    if (idx < nlive) {
+      int lb, ln0;
+      locate(idx, true, lb, ln0);
+      mine_s[tid] = (lb << 16) | (ln0 / TOK);
+    }
+  }
+  __syncthreads();
+  int tile_no = 0;
+  // next live tile of this workgroup (plain order: padding tiles beyond the halo are zero-filled on the way)
   auto next_tile = [&](int& t, int& b, int& n0) {
+    if (compact) {
+      if (t >= nlive) return false;
+      if (tile_no < WS_LIST) { const int v = mine_s[tile_no]; b = v >> 16; n0 = (v & 0xffff) * TOK; }
+      else locate(t, true, b, n0);
+      ++tile_no;
+      return true;
+    }
     for (; t < total; t += wgs_per_cotile) {
       b = t / tiles_n;
       n0 = (t - b * tiles_n) * TOK;
-      if (n0 < (b < 512 ? limit_s[b] : (a.skip_halo >= 0 ? a.lens[b] + a.skip_halo : 0x7fffffff))) return true;
-      if (!a.accumulate) {
-        for (int u = tid; u < TOK * 32; u += 512) {
-          const int row = u >> 5, q = u & 31;
-          const int n = n0 + row, co = co0 + q * 4;
-          if (n < a.N && co < a.Cout) {
-            if (a.y_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.Y) + ((size_t)b * a.N + n) * a.ldy + co) = make_uint2(0u, 0u);
-            else {
-              float* dst = a.Y + ((size_t)b * a.N + n) * a.ldy + co;
-              if (co + 3 < a.Cout) *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
-              else for (int e = 0; co + e < a.Cout; ++e) dst[e] = 0.f;
-            }
-          }
-        }
-      }
+      if (a.skip_halo < 0 || n0 < (limits_in_lds ? pre_s[b] : a.lens[b] + a.skip_halo)) return true;
+      if (!a.accumulate) zero_tile(b, n0);
     }
     return false;
   };
@@ -582,8 +646,6 @@ void launch_conv_ws(const ConvGemmArgs& a, hipStream_t s) {
 // so no two waves fetch the same weight fragment, every SIMD holds two waves, and LDS fragment traffic is what a 64x64 wave
 // tile would read.  The two K halves are summed through LDS at the end and each group finishes half of the tokens.
 // ------------------------------------------------------------------------------------------------
-constexpr int DK_MAX_B = 1024;    // batch rows the deep-K kernel can number live tiles for (larger batches: identity map)
-
 template <int TAPS, bool XH>
 __global__ __launch_bounds__(512) void conv_dk_kernel(const ConvGemmArgs a) {
   constexpr int PAD = (TAPS - 1) / 2;
