@@ -1153,27 +1153,41 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBf16Args 
   const bool do_bias = a.dbias != nullptr && ci0 == 0;
   float bsum0 = 0.f, bsum1 = 0.f;
   f32x4 dreg[D_IT], xreg[X_IT];
+  // Staging addresses: (unit -> tile row, channel) is fixed per thread, only the chunk's first row moves: a wave-uniform 64-bit
+  // chunk base (scalar unit) plus a 32-bit per-thread constant.
+  int drow[D_IT], dtoff[D_IT], xrow[X_IT], xtoff[X_IT];
+#pragma unroll
+  for (int it = 0; it < D_IT; ++it) {
+    const int u = tid + it * 256;
+    const int row = u / DU, c = co0 + (u % DU) * DE;
+    drow[it] = c < a.Cout ? row : 0x40000000;           // channel out of range: never in bounds
+    dtoff[it] = row * a.ldy + c;
+  }
+#pragma unroll
+  for (int it = 0; it < X_IT; ++it) {
+    const int u = tid + it * 256;
+    const int row = u / XU, c = ci0 + (u % XU) * XE;
+    xrow[it] = (u < XROWS * XU && c < a.Cin) ? row : 0x40000000;
+    xtoff[it] = row * a.ldx + c;
+  }
 #define DX_WG_LOAD(B_, NC_)                                                                                                   \
   {                                                                                                                           \
+    const ptrdiff_t dbase_ = ((ptrdiff_t)(B_) * a.N + (NC_)) * a.ldy;                                                         \
+    const ptrdiff_t xbase_ = ((ptrdiff_t)(B_) * a.N + (NC_) - PAD) * a.ldx;                                                   \
+    const int dlim_ = a.N - (NC_), xlo_ = PAD - (NC_), xhi_ = a.N - (NC_) + PAD;                                              \
     _Pragma("unroll") for (int it = 0; it < D_IT; ++it) {                                                                     \
-      const int u = tid + it * 256;                                                                                           \
-      const int row = u / DU, q = u % DU;                                                                                     \
-      const int n = (NC_) + row, c = co0 + q * DE;                                                                            \
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                                                    \
-      if (n < a.N && c < a.Cout) {                                                                                            \
-        if constexpr (DYH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.dY) + ((size_t)(B_) * a.N + n) * a.ldy + c); \
-        else v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.dY) + ((size_t)(B_) * a.N + n) * a.ldy + c); \
+      if (drow[it] < dlim_) {                                                                                                 \
+        if constexpr (DYH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.dY) + dbase_ + dtoff[it]);   \
+        else v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.dY) + dbase_ + dtoff[it]);                  \
       }                                                                                                                       \
       dreg[it] = v;                                                                                                           \
     }                                                                                                                         \
     _Pragma("unroll") for (int it = 0; it < X_IT; ++it) {                                                                     \
-      const int u = tid + it * 256;                                                                                           \
-      const int row = u / XU, q = u % XU;                                                                                     \
-      const int n = (NC_) - PAD + row, c = ci0 + q * XE;                                                                      \
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                                                    \
-      if (u < XROWS * XU && n >= 0 && n < a.N && c < a.Cin) {                                                                 \
-        if constexpr (XH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.X) + ((size_t)(B_) * a.N + n) * a.ldx + c); \
-        else v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.X) + ((size_t)(B_) * a.N + n) * a.ldx + c); \
+      if (xrow[it] >= xlo_ && xrow[it] < xhi_) {                                                                              \
+        if constexpr (XH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.X) + xbase_ + xtoff[it]);     \
+        else v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.X) + xbase_ + xtoff[it]);                   \
       }                                                                                                                       \
       xreg[it] = v;                                                                                                           \
     }                                                                                                                         \
