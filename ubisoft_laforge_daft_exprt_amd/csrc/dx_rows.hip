@@ -365,6 +365,7 @@ __global__ __launch_bounds__(256) void scalar_conv_wgrad_kernel(const float* __r
   float a0[3] = {0.f, 0.f, 0.f}, a1[3] = {0.f, 0.f, 0.f}, ab = 0.f;
   const float* x0 = s0 + (size_t)b * N;
   const float* x1 = s1 ? s1 + (size_t)b * N : nullptr;
+#pragma unroll 4
   for (int n = n_begin + half; n < n_end; n += 2) {
     float g = dout[((size_t)b * N + n) * ldd + c];
     if (rowscale) g *= rowscale[(size_t)b * N + n];
@@ -377,13 +378,25 @@ __global__ __launch_bounds__(256) void scalar_conv_wgrad_kernel(const float* __r
       if (x1) a1[t] += g * (in ? x1[m] : 0.f);
     }
   }
+  // the two row-halves fold in LDS first: every atomic here lands on one of ~1 k addresses, and same-address atomics
+  // serialise (672 blocks x 256 threads x 8 of them took most of this kernel's 49 us)
+  __shared__ float fold[7][D];
+  if (half == 1) {
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    atomicAdd(&dw0[c * 3 + t], a0[t]);
-    if (x1) atomicAdd(&dw1[c * 3 + t], a1[t]);
+    for (int t = 0; t < 3; ++t) { fold[t][c] = a0[t]; fold[3 + t][c] = a1[t]; }
+    fold[6][c] = ab;
   }
-  atomicAdd(&db0[c], ab);
-  if (x1) atomicAdd(&db1[c], ab);
+  __syncthreads();
+  if (half == 0) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const float v0 = a0[t] + fold[t][c];
+      if (v0 != 0.f) atomicAdd(&dw0[c * 3 + t], v0);
+      if (x1) { const float v1 = a1[t] + fold[3 + t][c]; if (v1 != 0.f) atomicAdd(&dw1[c * 3 + t], v1); }
+    }
+    const float vb = ab + fold[6][c];
+    if (vb != 0.f) { atomicAdd(&db0[c], vb); if (x1) atomicAdd(&db1[c], vb); }
+  }
 }
 
 // pooled[b,c] = sum_n x[b,n,c] / len_b.  One block per utterance, fixed summation order (bitwise reproducible).
@@ -627,7 +640,7 @@ int dx_scalar_conv_wgrad(const float* dout, int ldd, const float* rowscale, cons
   DX_REQUIRE(dout && s0 && lens && dw0 && db0, "dx_scalar_conv_wgrad: null pointer");
   DX_REQUIRE(D == 128 && ldd >= 0, "dx_scalar_conv_wgrad: hidden dim must be 128");  // ldd == 0: one row broadcast
   DX_REQUIRE(!s1 || (dw1 && db1), "dx_scalar_conv_wgrad: second stream needs its gradient buffers");
-  const int rpb = 64;
+  const int rpb = std::max(64, dx_cdiv(N, 4));       // few, long blocks: the cost is the number of same-address atomics
   hipLaunchKernelGGL(scalar_conv_wgrad_kernel, dim3(dx_cdiv(N, rpb), B), dim3(256), 0, (hipStream_t)stream,
                      dout, ldd, rowscale, s0, s1, lens, dw0, db0, dw1, db1, B, N, rpb);
   DX_LAUNCH_CHECK("dx_scalar_conv_wgrad");
