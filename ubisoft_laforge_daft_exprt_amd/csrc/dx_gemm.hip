@@ -1115,24 +1115,30 @@ __device__ __forceinline__ bf16x8 tr_fragment(const __bf16* tile, int row0, int 
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int TAPS, bool DYH, bool XH>
-__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBf16Args a) {
-  // workgroup: 128 output channels x 64 input channels x ALL taps; wave (2x2): 64 co x 32 ci -> 4 x 2 x TAPS MFMA tiles.
+// CIW = waves along the input channels: 2 -> 256 threads, 128 co x 64 ci per workgroup, two workgroups per CU;
+//                                      4 -> 512 threads, 128 co x 128 ci, ONE workgroup per CU (Cin % 128 == 0).
+// Per-workgroup records of the narrow form on 256 CUs: 384 workgroups leave half the CUs with two (110-120 k cycles) and half
+// with one (65-90 k, then idle), and two co-resident workgroups gain only 13 % over one (each stages its own copy of the same dY
+// tile).  The wide form puts the same two waves per SIMD on every CU with ONE dY tile per chunk: half the staging per MFMA.
+template <int TAPS, bool DYH, bool XH, int CIW>
+__global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel(const WgradBf16Args a) {
+  // wave: 64 co x 32 ci -> 4 x 2 x TAPS MFMA tiles; waves = 2 (co) x CIW (ci).
   // The dY tile and the (halo-extended) X tile are staged once per 64-token chunk and shared by the taps.
   constexpr int PAD = (TAPS - 1) / 2;
-  constexpr int CI_T = 64;
+  constexpr int NT = CIW * 128;
+  constexpr int CI_T = CIW * 32;
   constexpr int XROWS = WB_BK + TAPS - 1;
   constexpr int DU = DYH ? 16 : 32, DE = DYH ? 8 : 4;     // 16-byte global units per dY row (128 channels), elements per unit
-  constexpr int XU = XH ? 8 : 16, XE = XH ? 8 : 4;         // per X row (64 channels)
-  constexpr int D_IT = WB_BK * DU / 256;
-  constexpr int X_IT = (XROWS * XU + 255) / 256;
+  constexpr int XU = XH ? CI_T / 8 : CI_T / 4, XE = XH ? 8 : 4;   // per X row (CI_T channels)
+  constexpr int D_IT = WB_BK * DU / NT;
+  constexpr int X_IT = (XROWS * XU + NT - 1) / NT;
   __shared__ __attribute__((aligned(16))) __bf16 Ds[WB_BK * WB_LD];
   __shared__ __attribute__((aligned(16))) __bf16 Xs[(WB_BK + 8) * WB_LD];   // rows beyond the halo stay zero so every tr read is in bounds
   const int ci_tiles = (a.Cin + CI_T - 1) / CI_T;
   const int co0 = (blockIdx.x / ci_tiles) * TILE;
   const int ci0 = (blockIdx.x % ci_tiles) * CI_T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wc = wave >> 1, wt = wave & 1;
+  const int wc = wave / CIW, wt = wave % CIW;
   const int r = lane & 15, g = lane >> 4;
   const int chunks_per_row = (a.N + WB_BK - 1) / WB_BK;
   const int total = a.B * chunks_per_row;
@@ -1144,10 +1150,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBf16Args 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int u = tid; u < 8 * WB_LD; u += 256) Xs[WB_BK * WB_LD + u] = (__bf16)0.f;
+  for (int u = tid; u < 8 * WB_LD; u += NT) Xs[WB_BK * WB_LD + u] = (__bf16)0.f;
 
   // Fused bias gradient (column sums of the dY tile), done by the workgroups of input-channel tile 0 with ALL their threads
-  // (thread = channel pair x one quarter of the rows, 4-byte LDS reads).  As 128 threads x 64 two-byte reads it made those
+  // (thread = channel pair x one slice of the rows, 4-byte LDS reads).  As 128 threads x 64 two-byte reads it made those
   // workgroups' first two waves ~1.2 k cycles per chunk slower than everyone else: the kernel's tail.  (Spreading the sums
   // over all sibling workgroups instead was far worse: 100 k atomics on the same 128 addresses.)
   const bool do_bias = a.dbias != nullptr && ci0 == 0;
@@ -1158,14 +1164,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBf16Args 
   int drow[D_IT], dtoff[D_IT], xrow[X_IT], xtoff[X_IT];
 #pragma unroll
   for (int it = 0; it < D_IT; ++it) {
-    const int u = tid + it * 256;
+    const int u = tid + it * NT;
     const int row = u / DU, c = co0 + (u % DU) * DE;
     drow[it] = c < a.Cout ? row : 0x40000000;           // channel out of range: never in bounds
     dtoff[it] = row * a.ldy + c;
   }
 #pragma unroll
   for (int it = 0; it < X_IT; ++it) {
-    const int u = tid + it * 256;
+    const int u = tid + it * NT;
     const int row = u / XU, c = ci0 + (u % XU) * XE;
     xrow[it] = (u < XROWS * XU && c < a.Cin) ? row : 0x40000000;
     xtoff[it] = row * a.ldx + c;
@@ -1195,13 +1201,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBf16Args 
 #define DX_WG_STORE()                                                                                                         \
   {                                                                                                                           \
     _Pragma("unroll") for (int it = 0; it < D_IT; ++it) {                                                                     \
-      const int u = tid + it * 256;                                                                                           \
+      const int u = tid + it * NT;                                                                                           \
       const int row = u / DU, q = u % DU;                                                                                     \
       if constexpr (DYH) *reinterpret_cast<f32x4*>(Ds + row * WB_LD + q * 8) = dreg[it];                                      \
       else *reinterpret_cast<uint2*>(Ds + row * WB_LD + q * 4) = pack_bf16x4v(dreg[it]);                                      \
     }                                                                                                                         \
     _Pragma("unroll") for (int it = 0; it < X_IT; ++it) {                                                                     \
-      const int u = tid + it * 256;                                                                                           \
+      const int u = tid + it * NT;                                                                                           \
       const int row = u / XU, q = u % XU;                                                                                     \
       if (u < XROWS * XU) {                                                                                                   \
         if constexpr (XH) *reinterpret_cast<f32x4*>(Xs + row * WB_LD + q * 8) = xreg[it];                                     \
@@ -1213,7 +1219,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBf16Args 
   // chunk walk of this split-K slice (interleaved: every slice sees a mix of utterance lengths).  The per-utterance limits sit in
   // LDS and (b, chunk-in-row) advance incrementally: a scalar global load + an integer division per chunk cost ~2 k cycles here.
   __shared__ int limit_s[512];
-  for (int i = tid; i < min(a.B, 512); i += 256) limit_s[i] = a.skip_halo >= 0 ? a.lens[i] + a.skip_halo : 0x7fffffff;
+  for (int i = tid; i < min(a.B, 512); i += NT) limit_s[i] = a.skip_halo >= 0 ? a.lens[i] + a.skip_halo : 0x7fffffff;
   __syncthreads();
   const int step_b = a.ksplit / chunks_per_row, step_k = a.ksplit - step_b * chunks_per_row;
   int c = blockIdx.z, b = c / chunks_per_row, kc = c - b * chunks_per_row, nc = 0;
@@ -1232,9 +1238,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBf16Args 
     while (c < total && !live()) advance();
     if (c < total) DX_WG_LOAD(b, nc);
     if (do_bias) {
-      const __bf16* col = Ds + (tid >> 6) * (WB_BK / 4) * WB_LD + (tid & 63) * 2;
+      const __bf16* col = Ds + (tid >> 6) * (WB_BK / (NT / 64)) * WB_LD + (tid & 63) * 2;
 #pragma unroll
-      for (int k = 0; k < WB_BK / 4; ++k) {
+      for (int k = 0; k < WB_BK / (NT / 64); ++k) {
         const unsigned v = *reinterpret_cast<const unsigned*>(col + k * WB_LD);
         bsum0 += __builtin_bit_cast(float, v << 16);
         bsum1 += __builtin_bit_cast(float, v & 0xffff0000u);
@@ -1273,14 +1279,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradBf16Args 
           if (co < a.Cout && acc[t][i][j][e] != 0.f) atomicAdd(&a.G[((size_t)t * a.Cout + co) * a.Cin + ci], acc[t][i][j][e]);
         }
       }
-  if (do_bias) {                                         // workgroup-uniform: fold the four row quarters, one atomic per channel
+  if (do_bias) {                                         // workgroup-uniform: fold the row slices, one atomic per channel
     float* red = reinterpret_cast<float*>(Ds);           // the chunk loop is over: its last barrier has retired every tile read
     __syncthreads();
     red[(tid >> 6) * TILE + (tid & 63) * 2] = bsum0;
     red[(tid >> 6) * TILE + (tid & 63) * 2 + 1] = bsum1;
     __syncthreads();
     if (tid < TILE && co0 + tid < a.Cout) {
-      const float t = (red[tid] + red[TILE + tid]) + (red[2 * TILE + tid] + red[3 * TILE + tid]);
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < NT / 64; ++q) t += red[q * TILE + tid];
       if (t != 0.f) atomicAdd(&a.dbias[co0 + tid], t);
     }
   }
@@ -1497,20 +1505,26 @@ int dx_conv_wgrad(const void* dY, int ldy, const void* X, int ldx, float* G,
     DX_REQUIRE(B > 0 && N > 0 && Cin > 0 && Cout > 0 && (taps == 1 || taps == 3), "dx_conv_wgrad: bad dims");
     DX_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)dY % 16) == 0, "dx_conv_wgrad: pointers must be 16-byte aligned");
     DX_REQUIRE(skip_halo < 0 || lens, "dx_conv_wgrad: skip_halo needs lens");
-    const int tiles = dx_cdiv(Cout, TILE) * dx_cdiv(Cin, 64);
+    static const int use_wide = getenv("DX_WGRAD_WIDE") ? atoi(getenv("DX_WGRAD_WIDE")) : 1;
+    // 512-thread workgroups with 128 input channels each: measured better only where the output is large enough that few token
+    // slices are needed anyway (prenet 1024 x 1024: 308 -> 239 us); the 128-wide layers stay on the narrow form (59 vs 67 us)
+    const bool wide = use_wide && (Cin % 128) == 0 && dx_cdiv(Cout, TILE) * dx_cdiv(Cin, 64) >= 64;
+    const int tiles = dx_cdiv(Cout, TILE) * dx_cdiv(Cin, wide ? 128 : 64);
     const int total_chunks = B * dx_cdiv(N, WB_BK);
     static const int target_blocks = getenv("DX_WGRAD_BLOCKS") ? atoi(getenv("DX_WGRAD_BLOCKS")) : 384;   // split-K partials are fp32 atomics (~1.3 TB/s chip-wide): 384 blocks measured best (256..1024 swept)
-    const int ksplit = std::max(1, std::min(total_chunks, dx_cdiv(target_blocks, tiles)));
+    static const int target_wide = getenv("DX_WGRAD_BLOCKS_WIDE") ? atoi(getenv("DX_WGRAD_BLOCKS_WIDE")) : 256;   // one per CU
+    const int ksplit = std::max(1, std::min(total_chunks, dx_cdiv(wide ? target_wide : target_blocks, tiles)));
     WgradBf16Args a{dY, ldy, dy_bf16, X, ldx, x_bf16, G, B, N, Cin, Cout, ksplit, lens, skip_halo, dbias};
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(tiles, 1, ksplit);
     dx_prof_begin(DX_PROF_WGRAD_GEMM, s);
-#define DX_WG_LAUNCH(TAPS_)                                                                                              \
-    if (dy_bf16 && x_bf16) hipLaunchKernelGGL((wgrad_bf16_kernel<TAPS_, true, true>), grid, dim3(256), 0, s, a);            \
-    else if (dy_bf16) hipLaunchKernelGGL((wgrad_bf16_kernel<TAPS_, true, false>), grid, dim3(256), 0, s, a);                \
-    else if (x_bf16) hipLaunchKernelGGL((wgrad_bf16_kernel<TAPS_, false, true>), grid, dim3(256), 0, s, a);                 \
-    else hipLaunchKernelGGL((wgrad_bf16_kernel<TAPS_, false, false>), grid, dim3(256), 0, s, a);
-    if (taps == 3) { DX_WG_LAUNCH(3) } else { DX_WG_LAUNCH(1) }
+#define DX_WG_LAUNCH(TAPS_, CIW_)                                                                                        \
+    if (dy_bf16 && x_bf16) hipLaunchKernelGGL((wgrad_bf16_kernel<TAPS_, true, true, CIW_>), grid, dim3(CIW_ * 128), 0, s, a);   \
+    else if (dy_bf16) hipLaunchKernelGGL((wgrad_bf16_kernel<TAPS_, true, false, CIW_>), grid, dim3(CIW_ * 128), 0, s, a);       \
+    else if (x_bf16) hipLaunchKernelGGL((wgrad_bf16_kernel<TAPS_, false, true, CIW_>), grid, dim3(CIW_ * 128), 0, s, a);        \
+    else hipLaunchKernelGGL((wgrad_bf16_kernel<TAPS_, false, false, CIW_>), grid, dim3(CIW_ * 128), 0, s, a);
+    if (wide) { if (taps == 3) { DX_WG_LAUNCH(3, 4) } else { DX_WG_LAUNCH(1, 4) } }
+    else { if (taps == 3) { DX_WG_LAUNCH(3, 2) } else { DX_WG_LAUNCH(1, 2) } }
 #undef DX_WG_LAUNCH
     dx_prof_end(DX_PROF_WGRAD_GEMM, s);
     DX_LAUNCH_CHECK("dx_conv_wgrad(bf16)");
