@@ -726,17 +726,20 @@ __global__ __launch_bounds__(512) void conv_dk_kernel(const ConvGemmArgs a) {
   const int nchunks = a.CinP / 64;
   // Every staging access is unconditional (addresses are clamped, zeros are selected in when the value is stored): loads
   // inside divergent branches make the compiler give up counting vmcnt and drain the whole prefetch queue at each use.
-  size_t xoff[X_IT]; int xlds[X_IT], xci[X_IT];                     // xci < 0: row outside the batch row (conv zero padding)
+  // Addresses are a wave-uniform base (scalar unit) + a 32-bit per-thread element offset: no vector arithmetic per load (the
+  // host routes Cin % 64 != 0 or >= 2^31-element tensors to the tiled kernel).  Rows outside the batch row read row 0 of the
+  // tensor instead and are zeroed at the LDS store, which only the first / last tile of a batch row ever needs.
+  int xoff[X_IT], xlds[X_IT]; bool xpad[X_IT];
 #pragma unroll
   for (int it = 0; it < X_IT; ++it) {
     const int u = min(tid + it * 512, XROWS * XU - 1);              // surplus slots repeat the last unit (same value, same place)
     const int row = u / XU, q = u % XU;
     const int n = n0 + row - PAD;
-    const bool ok = n >= 0 && n < a.N;
-    xoff[it] = ok ? ((size_t)b * a.N + n) * a.ldx + q * XE : 0;
-    xci[it] = ok ? q * XE : -1;
+    xpad[it] = n < 0 || n >= a.N;
+    xoff[it] = xpad[it] ? q * XE : (b * a.N + n) * a.ldx + q * XE;
     xlds[it] = XH ? lds_off(row, q) : lds_off(row, q >> 1) + ((q & 1) << 3);
   }
+  const bool edge_tile = n0 < PAD || n0 + TOK + PAD > a.N;          // wave-uniform
   // fragment (tap, i) of stage ch: element offset wbase + ((tap * (CoutP/16) + i) * (CinP/32) + 2 * ch) * 512
   const __bf16* const wwave = Wp + ((size_t)((co0 >> 4) + wq * 2) * (a.CinP >> 5) + kg) * 512;      // wave-uniform
   const size_t wtap = (size_t)(a.CoutP >> 4) * (a.CinP >> 5) * 512, wrow = (size_t)(a.CinP >> 5) * 512;
@@ -753,15 +756,14 @@ __global__ __launch_bounds__(512) void conv_dk_kernel(const ConvGemmArgs a) {
 #define DK_LOAD_X1(IT, CH, XR)                                                                                       \
   {                                                                                                                  \
     const int ch_ = min((CH), nchunks - 1) * 64;                                                                     \
-    const size_t off_ = (xci[IT] >= 0 && ch_ + xci[IT] < a.Cin) ? xoff[IT] + ch_ : 0;                                \
-    if constexpr (XH) XR[IT] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.X) + off_);         \
-    else XR[IT] = *reinterpret_cast<const f32x4*>(a.X + off_);                                                       \
+    if constexpr (XH) XR[IT] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.X) + ch_ + xoff[IT]); \
+    else XR[IT] = *reinterpret_cast<const f32x4*>(a.X + ch_ + xoff[IT]);                                             \
   }
 #define DK_LOAD_X(CH, XR) { _Pragma("unroll") for (int it = 0; it < X_IT; ++it) DK_LOAD_X1(it, CH, XR) }
 #define DK_STORE_X1(IT, CH, BASE, XR)                                                                                \
   {                                                                                                                  \
-    const int ch_ = min((CH), nchunks - 1) * 64;                                                                     \
-    const f32x4 v_ = (xci[IT] >= 0 && ch_ + xci[IT] < a.Cin) ? XR[IT] : f32x4{0.f, 0.f, 0.f, 0.f};                   \
+    f32x4 v_ = XR[IT];                                                                                               \
+    if (edge_tile) v_ = xpad[IT] ? f32x4{0.f, 0.f, 0.f, 0.f} : v_;                                                   \
     if constexpr (XH) *reinterpret_cast<f32x4*>((BASE) + xlds[IT]) = v_;                                             \
     else *reinterpret_cast<uint2*>((BASE) + xlds[IT]) = pack_bf16x4v(v_);                                            \
   }
@@ -1480,7 +1482,7 @@ int dx_conv_gemm(const void* Xv, int ldx, const void* Wp, const float* bias, voi
   static const int use_ws = getenv("DX_CONV_WS") ? atoi(getenv("DX_CONV_WS")) : 1;
   static const int use_dk = getenv("DX_CONV_DK") ? atoi(getenv("DX_CONV_DK")) : 1;
   // deep-K layers: weights straight from the fragment-major pack into registers, live tiles numbered first
-  if (bf16 && use_dk && d[1] >= 256) {
+  if (bf16 && use_dk && d[1] >= 256 && (Cin % 64) == 0 && (long)B * N * ldx < (1L << 31)) {
     if (x_bf16) { if (taps == 3) launch_conv_dk<3, true>(a, s); else launch_conv_dk<1, true>(a, s); }
     else { if (taps == 3) launch_conv_dk<3, false>(a, s); else launch_conv_dk<1, false>(a, s); }
   } else if (bf16 && use_ws && d[1] == 128 && (long)B * dx_cdiv(N, 128) >= 64) {      // short-K layers: weight-stationary persistent kernel
