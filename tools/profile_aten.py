@@ -66,7 +66,7 @@ print('python-level sources in one step:')
 for k, v in sorted(srcs.items(), key=lambda kv: (kv[0][0], -kv[1])):
     if k[0] not in ('empty', 'empty_like'): print('  %4d  %-18s %s' % (v, k[0], k[1]))
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     step(3)
     torch.cuda.synchronize()
 cnt = collections.Counter(); dur = collections.Counter()
@@ -81,3 +81,11 @@ tot = sum(dur.values())
 print('aten device time per step: %.1f us over %d ops' % (tot, sum(cnt.values())))
 for k, v in dur.most_common(45):
     print('%8.1f us %4d  %-28s %s' % (v, cnt[k], k[0], k[1]))
+print('by op and input shapes:')
+shp = collections.Counter(); shpd = collections.Counter()
+for ev in prof.events():
+    if ev.device_type == torch.autograd.DeviceType.CPU and ev.name.startswith('aten::') and ev.device_time_total > 0 and not any(c.name.startswith('aten::') and c.device_time_total > 0 for c in ev.cpu_children):
+        k = (ev.name, str(ev.input_shapes)[:90])
+        shp[k] += 1; shpd[k] += ev.device_time_total
+for k, v in shpd.most_common(40):
+    print('%8.1f us %4d  %-22s %s' % (v, shp[k], k[0], k[1]))

@@ -259,8 +259,9 @@ class PhonemeEncoder(nn.Module):
         lens = input_lengths if isinstance(input_lengths, Lengths) else Lengths(input_lengths)
         pe = positional_table(self.cfg['hidden_embed_dim'], x.device)
         h = Fx.EmbedPosFn.apply(x, self.symbols_embedding.weight, pe, lens)
+        film = None if film_params is None else Fx.SplitFilmFn.apply(film_params)
         for i, block in enumerate(self.blocks):
-            h = block(h, None if film_params is None else film_params[:, i, :], lens)
+            h = block(h, None if film is None else film[i], lens)
         return h
 
 
@@ -306,8 +307,9 @@ class FrameDecoder(nn.Module):
         lens = output_lengths if isinstance(output_lengths, Lengths) else Lengths(output_lengths)
         pe = positional_table(self.cfg['hidden_embed_dim'], x.device)
         h = Fx.AddPosFn.apply(x, pe, lens)
+        film = Fx.SplitFilmFn.apply(film_params)
         for i, block in enumerate(self.blocks):
-            h = block(h, film_params[:, i, :], lens)
+            h = block(h, film[i], lens)
         p = self.projection.linear_layer
         return Fx.MelProjectionFn.apply(h, p.weight, p.bias, p.pack, lens)
 
