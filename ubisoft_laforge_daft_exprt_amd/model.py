@@ -205,6 +205,20 @@ class SpeakerClassifier(nn.Module):
         return Fx.PaddedLinearFn.apply(h, last.weight, last.bias, self._padded)
 
 
+class FilmSet(list):
+    """Per-block FiLM tensors (B, 2C) of one module, plus the (B, nb, 2C) tensor the reference returns for it."""
+
+    def __init__(self, blocks, tensor):
+        super().__init__(blocks)
+        self.tensor = tensor
+
+
+def _film_blocks(film_params):
+    if film_params is None or isinstance(film_params, FilmSet):
+        return film_params
+    return Fx.SplitFilmFn.apply(film_params)
+
+
 class StyleAdapter(nn.Module):
     """reference model.py:719-806"""
 
@@ -229,6 +243,25 @@ class StyleAdapter(nn.Module):
         betas = self.betas_predictor(style_embedding)
         out, col, blk = {}, 0, 0
         B = gammas.shape[0]
+        chans = {ch for _, ch in self.module_params.values()}
+        if len(chans) == 1:
+            # every module has the same width: the scalar post-multiplier affine, the (gamma | beta) concatenation and the split
+            # into per-block tensors are done ONCE for all blocks (same element-wise arithmetic, a third of the glue launches)
+            ch = chans.pop()
+            nb_all = sum(nb for nb, _ in self.module_params.values())
+            g = gammas.view(B, nb_all, ch)
+            b = betas.view(B, nb_all, ch)
+            if self.post_mult_weight != 0.0:
+                g = self.post_multipliers[0][None, :, None] * g + 1
+                b = self.post_multipliers[1][None, :, None] * b
+            else:
+                g = g + 1
+            film_all = torch.cat((g, b), dim=2)
+            blocks = Fx.SplitFilmFn.apply(film_all)
+            for name, (nb, _) in self.module_params.items():
+                out[name] = FilmSet(blocks[blk:blk + nb], film_all[:, blk:blk + nb])
+                blk += nb
+            return out
         for name, (nb, ch) in self.module_params.items():
             # (B, nb, ch) scalar post-multiplier affine: O(B * 1024) element-wise glue on the autograd tape
             g = gammas[:, col:col + nb * ch].view(B, nb, ch)
@@ -259,7 +292,7 @@ class PhonemeEncoder(nn.Module):
         lens = input_lengths if isinstance(input_lengths, Lengths) else Lengths(input_lengths)
         pe = positional_table(self.cfg['hidden_embed_dim'], x.device)
         h = Fx.EmbedPosFn.apply(x, self.symbols_embedding.weight, pe, lens)
-        film = None if film_params is None else Fx.SplitFilmFn.apply(film_params)
+        film = _film_blocks(film_params)
         for i, block in enumerate(self.blocks):
             h = block(h, None if film is None else film[i], lens)
         return h
@@ -307,7 +340,7 @@ class FrameDecoder(nn.Module):
         lens = output_lengths if isinstance(output_lengths, Lengths) else Lengths(output_lengths)
         pe = positional_table(self.cfg['hidden_embed_dim'], x.device)
         h = Fx.AddPosFn.apply(x, pe, lens)
-        film = Fx.SplitFilmFn.apply(film_params)
+        film = _film_blocks(film_params)
         for i, block in enumerate(self.blocks):
             h = block(h, film[i], lens)
         p = self.projection.linear_layer
@@ -390,7 +423,8 @@ class DaftExprt(nn.Module):
         x, weights = self.gaussian_upsampling(enc_outputs, durations_float, durations_int, symbols_energy, symbols_pitch,
                                               in_lens, film_params=None, n_frames=out_lens.max)
         mel_preds = self.frame_decoder(x, film['frame_decoder'], out_lens)
-        film_params = [self.style_adapter.post_multipliers, None, None, film['frame_decoder']]
+        fd = film['frame_decoder']
+        film_params = [self.style_adapter.post_multipliers, None, None, fd.tensor if isinstance(fd, FilmSet) else fd]
         encoder_preds = [durations_float, symbols_energy, symbols_pitch, input_lengths]
         decoder_preds = [mel_preds, output_lengths]
         return speaker_preds, film_params, encoder_preds, decoder_preds, weights
