@@ -219,6 +219,7 @@ class AccentFrontFn(torch.autograd.Function):
         out = ops.accent_sum(y2, energy, pitch, we, be, wp, bp, pe, lens.i32)
         ctx.save_for_backward(x0, h0, m0, r0, y0, h1, m1, r1, y1, h2, m2, r2, energy, pitch, l0_w, l0_b, l1_w, l1_b, l2_w, l2_b)
         ctx.lens, ctx.packs, ctx.p, ctx.seeds = lens, packs, p, seeds
+        ctx.emb_params = (we, be, wp, bp)
         return out
 
     @staticmethod
@@ -226,7 +227,7 @@ class AccentFrontFn(torch.autograd.Function):
         x0, h0, m0, r0, y0, h1, m1, r1, y1, h2, m2, r2, energy, pitch, l0_w, l0_b, l1_w, l1_b, l2_w, l2_b = ctx.saved_tensors
         lens, packs, p, seeds = ctx.lens, ctx.packs, ctx.p, ctx.seeds
         dout = ops.mask_rows(dout.contiguous(), lens.i32)
-        dwe, dbe, dwp, dbp = ops.scalar_conv_wgrad(dout, energy, pitch, lens.i32)
+        dwe, dbe, dwp, dbp = ops.scalar_conv_wgrad(dout, energy, pitch, lens.i32, sinks=tuple(_sink(q) for q in ctx.emb_params))
         L = lens.i32
         P = packs.get('params', {})
         sk = {k: _sink(v) for k, v in P.items()}
@@ -318,6 +319,7 @@ class GaussianUpsampleFn(torch.autograd.Function):
         xup, weights = ops.upsample_fwd(xs, mu, sigma, lens.i32, n_frames)
         ctx.save_for_backward(xs, z, sigma, mu, weights, dur_float, energy, pitch, wd, bd, wr)
         ctx.lens = lens
+        ctx.params = (wd, bd, we, be, wp, bp, wr, br)
         ctx.mark_non_differentiable(weights)
         return xup, weights
 
@@ -326,11 +328,15 @@ class GaussianUpsampleFn(torch.autograd.Function):
         xs, z, sigma, mu, weights, dur_float, energy, pitch, wd, bd, wr = ctx.saved_tensors
         lens = ctx.lens
         dxs, dsigma = ops.upsample_bwd(dxup.contiguous(), xs, mu, sigma, weights, lens.i32)
-        dxs, dz, dwr, dbr = ops.upsample_sym_bwd(dxs, dsigma, xs, z, dur_float, lens.i32, wd, bd, wr)
-        dwe, dbe, dwp, dbp = ops.scalar_conv_wgrad(dxs, energy, pitch, lens.i32)
-        dwd, dbd, _, _ = ops.scalar_conv_wgrad(wr.reshape(-1), dur_float, None, lens.i32, rowscale=dz)
+        pwd, pbd, pwe, pbe, pwp, pbp, pwr, pbr = ctx.params
+        swr = _sink(pwr)
+        dxs, dz, dwr, dbr = ops.upsample_sym_bwd(dxs, dsigma, xs, z, dur_float, lens.i32, wd, bd, wr,
+                                                 dwr_sink=None if swr is None else swr.view(-1), dbr_sink=_sink(pbr))
+        dwe, dbe, dwp, dbp = ops.scalar_conv_wgrad(dxs, energy, pitch, lens.i32, sinks=(_sink(pwe), _sink(pbe), _sink(pwp), _sink(pbp)))
+        dwd, dbd, _, _ = ops.scalar_conv_wgrad(wr.reshape(-1), dur_float, None, lens.i32, rowscale=dz, sinks=(_sink(pwd), _sink(pbd), None, None))
         denc = ops.mask_rows(dxs, lens.i32)  # the encoder output is zero-masked; rows >= len carry no gradient upstream
-        return denc, None, None, None, None, None, None, dwd, dbd, dwe, dbe, dwp, dbp, dwr.view(1, -1), dbr
+        return (denc, None, None, None, None, None, None, dwd, dbd, dwe, dbe, dwp, dbp,
+                None if dwr is None else dwr.view(1, -1), dbr)
 
 
 class MelProjectionFn(torch.autograd.Function):

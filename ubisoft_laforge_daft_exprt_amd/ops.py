@@ -322,18 +322,21 @@ def accent_sum(prenet, energy, pitch, we, be, wp, bp, pe, lens):
     return out
 
 
-def scalar_conv_wgrad(dout, s0, s1, lens, rowscale=None):
-    """Gradients of Conv1d(1->128, k=3) weights/biases fed by the scalar streams s0 (and s1) given dout (B, N, 128)."""
+def scalar_conv_wgrad(dout, s0, s1, lens, rowscale=None, sinks=None):
+    """Gradients of Conv1d(1->128, k=3) weights/biases fed by the scalar streams s0 (and s1) given dout (B, N, 128).
+    ``sinks``: (dw0, db0, dw1, db1) pre-zeroed ``.grad`` tensors (or None each) that the kernel accumulates into directly;
+    the corresponding return value is then None."""
     B, N = s0.shape
     D = 128
     dev = s0.device
-    dw0 = torch.zeros(D, 1, 3, dtype=torch.float32, device=dev)
-    db0 = torch.zeros(D, dtype=torch.float32, device=dev)
-    dw1 = torch.zeros(D, 1, 3, dtype=torch.float32, device=dev) if s1 is not None else None
-    db1 = torch.zeros(D, dtype=torch.float32, device=dev) if s1 is not None else None
+    sinks = sinks or (None, None, None, None)
+    dw0 = sinks[0] if sinks[0] is not None else torch.zeros(D, 1, 3, dtype=torch.float32, device=dev)
+    db0 = sinks[1] if sinks[1] is not None else torch.zeros(D, dtype=torch.float32, device=dev)
+    dw1 = (sinks[2] if sinks[2] is not None else torch.zeros(D, 1, 3, dtype=torch.float32, device=dev)) if s1 is not None else None
+    db1 = (sinks[3] if sinks[3] is not None else torch.zeros(D, dtype=torch.float32, device=dev)) if s1 is not None else None
     ldd = dout.stride(-2) if dout.dim() == 3 else 0  # a 1-D dout (D,) is broadcast over every row
     lib().dx_scalar_conv_wgrad(_p(dout), ldd, _p(rowscale), _p(s0), _p(s1), _p(lens), _p(dw0), _p(db0), _p(dw1), _p(db1), B, N, D, _stream())
-    return dw0, db0, dw1, db1
+    return tuple(None if sk is not None else t for sk, t in zip(sinks, (dw0, db0, dw1, db1)))
 
 
 def mean_pool(x, lens):
@@ -407,15 +410,16 @@ def upsample_bwd(dxup, xs, mu, sigma, weights, lens):
     return dxs, dsigma
 
 
-def upsample_sym_bwd(dxs, dsigma, xs, z, dur, lens, wd, bd, wr):
+def upsample_sym_bwd(dxs, dsigma, xs, z, dur, lens, wd, bd, wr, dwr_sink=None, dbr_sink=None):
+    """``dwr_sink`` / ``dbr_sink``: pre-zeroed ``.grad`` tensors to accumulate into (the returned dwr / dbr is then None)."""
     B, L, D = xs.shape
     dxs_out = torch.empty_like(xs)
     dz = torch.empty(B, L, dtype=torch.float32, device=xs.device)
-    dwr = torch.zeros(D, dtype=torch.float32, device=xs.device)
-    dbr = torch.zeros(1, dtype=torch.float32, device=xs.device)
+    dwr = dwr_sink if dwr_sink is not None else torch.zeros(D, dtype=torch.float32, device=xs.device)
+    dbr = dbr_sink if dbr_sink is not None else torch.zeros(1, dtype=torch.float32, device=xs.device)
     lib().dx_upsample_sym_bwd(_p(dxs), _p(dsigma), _p(xs), _p(z), _p(dur), _p(lens), _p(wd), _p(bd), _p(wr), _p(dxs_out), _p(dz), _p(dwr), _p(dbr),
                               B, L, D, _stream())
-    return dxs_out, dz, dwr, dbr
+    return dxs_out, dz, (None if dwr_sink is not None else dwr), (None if dbr_sink is not None else dbr)
 
 
 def mel_stats(mel_pred, mel_target):
