@@ -1513,9 +1513,13 @@ int dx_conv_wgrad(const void* dY, int ldy, const void* X, int ldx, float* G,
     const bool wide = use_wide && (Cin % 128) == 0 && dx_cdiv(Cout, TILE) * dx_cdiv(Cin, 64) >= 64;
     const int tiles = dx_cdiv(Cout, TILE) * dx_cdiv(Cin, wide ? 128 : 64);
     const int total_chunks = B * dx_cdiv(N, WB_BK);
-    static const int target_blocks = getenv("DX_WGRAD_BLOCKS") ? atoi(getenv("DX_WGRAD_BLOCKS")) : 384;   // split-K partials are fp32 atomics (~1.3 TB/s chip-wide): 384 blocks measured best (256..1024 swept)
+    // split-K partials are fp32 atomics (~1.3 TB/s chip-wide), so the split is sized by atomic traffic, not by "as many as fit";
+    // per-kernel rocprof sweeps (r01-g build): k = 3 layers 192 / 256 / 320 / 384 blocks -> 50.0 / 47.6 / 48.8 / 50.2 us,
+    // k = 1 layers 96 / 128 / 160 / 192 / 256 / 384 -> 24.9 / 20.9 / 19.5 / 18.8 / 19.5 / 22.1 us
+    static const int target_blocks = getenv("DX_WGRAD_BLOCKS") ? atoi(getenv("DX_WGRAD_BLOCKS")) : 256;
     static const int target_wide = getenv("DX_WGRAD_BLOCKS_WIDE") ? atoi(getenv("DX_WGRAD_BLOCKS_WIDE")) : 256;   // one per CU
-    const int ksplit = std::max(1, std::min(total_chunks, dx_cdiv(wide ? target_wide : target_blocks, tiles)));
+    static const int target_k1 = getenv("DX_WGRAD_BLOCKS_K1") ? atoi(getenv("DX_WGRAD_BLOCKS_K1")) : 192;
+    const int ksplit = std::max(1, std::min(total_chunks, dx_cdiv(wide ? target_wide : (taps == 1 ? target_k1 : target_blocks), tiles)));
     WgradBf16Args a{dY, ldy, dy_bf16, X, ldx, x_bf16, G, B, N, Cin, Cout, ksplit, lens, skip_halo, dbias};
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(tiles, 1, ksplit);
