@@ -125,7 +125,8 @@ class PackedWeight:
 
     def _current_key(self):
         w = self.weight
-        return (w._version, w.data_ptr(), _PRECISION['bf16'], _PACK_EPOCH[0])
+        # the pack epoch stands for "an optimiser step happened": frozen weights (the pitch predictor of the loss) are not part of it
+        return (w._version, w.data_ptr(), _PRECISION['bf16'], _PACK_EPOCH[0] if w.requires_grad else 0)
 
     def _ensure_buffers(self):
         w = self.weight
