@@ -1452,7 +1452,8 @@ int launch_conv(const ConvGemmArgs& a, hipStream_t s) {
   // narrow outputs (Cout <= 128: conv2, out-proj, mel projection ...) launch few workgroups: in exact-f32 mode (MFMA-paced)
   // 64-token tiles fill the chip better (measured 405 -> 354 us on the FF conv2); in bf16 mode the 128-token tile stays ahead
   // (62 vs 79 us) because the weight tile is re-staged half as often.
-  static const long small_below = getenv("DX_CONV_SMALL_BELOW") ? atol(getenv("DX_CONV_SMALL_BELOW")) : (sizeof(T) == 4 ? 1024 : 0);
+  // (bf16, k = 1, few workgroups - the phoneme-level Linear layers: 64-token tiles measured 9.6 -> 7.7 us; bf16 k = 3 stays at 128)
+  static const long small_below = getenv("DX_CONV_SMALL_BELOW") ? atol(getenv("DX_CONV_SMALL_BELOW")) : ((sizeof(T) == 4 || TAPS == 1) ? 1024 : 0);
   const bool small = (long)a.B * dx_cdiv(a.N, TILE) * (a.CoutP / TILE) < small_below;
   if constexpr (sizeof(T) == 2) {
     if (a.x_bf16) { if (small) launch_conv_inst<T, TAPS, 64, true>(a, s); else launch_conv_inst<T, TAPS, 128, true>(a, s); return DX_OK; }
@@ -1533,11 +1534,12 @@ int dx_conv_gemm(const void* Xv, int ldx, const void* Wp, const float* bias, voi
   dx_prof_begin(DX_PROF_CONV_GEMM, s);
   static const int use_ws = getenv("DX_CONV_WS") ? atoi(getenv("DX_CONV_WS")) : 1;
   static const int use_dk = getenv("DX_CONV_DK") ? atoi(getenv("DX_CONV_DK")) : 1;
+  static const int ws_min_tiles = getenv("DX_CONV_WS_MIN_TILES") ? atoi(getenv("DX_CONV_WS_MIN_TILES")) : 64;
   // deep-K layers: weights straight from the fragment-major pack into registers, live tiles numbered first
   if (bf16 && use_dk && d[1] >= 256 && (Cin % 64) == 0 && (long)B * N * ldx < (1L << 31)) {
     if (x_bf16) { if (taps == 3) launch_conv_dk<3, true>(a, s); else launch_conv_dk<1, true>(a, s); }
     else { if (taps == 3) launch_conv_dk<3, false>(a, s); else launch_conv_dk<1, false>(a, s); }
-  } else if (bf16 && use_ws && d[1] == 128 && (long)B * dx_cdiv(N, 128) >= 64) {      // short-K layers: weight-stationary persistent kernel
+  } else if (bf16 && use_ws && d[1] == 128 && (long)B * dx_cdiv(N, 128) >= ws_min_tiles) {      // short-K layers: weight-stationary persistent kernel
     if (x_bf16) { if (taps == 3) launch_conv_ws<3, true>(a, s); else launch_conv_ws<1, true>(a, s); }
     else { if (taps == 3) launch_conv_ws<3, false>(a, s); else launch_conv_ws<1, false>(a, s); }
   } else if (bf16) { if (taps == 3) launch_conv<__bf16, 3>(a, s); else launch_conv<__bf16, 1>(a, s); }
