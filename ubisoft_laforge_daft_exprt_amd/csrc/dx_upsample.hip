@@ -9,6 +9,7 @@
 // HBM traffic (fp32): reads B*L*D + 4*B*L, writes B*T*D + B*L*T  (35 MB at B=48, L=120, T=840; the reference
 // materialises 2 GB).  One workgroup owns TT frames of one utterance and keeps the [L][TT] weight tile in LDS.
 #include "dx_common.h"
+#include <stdlib.h>
 #include <algorithm>
 
 namespace {
@@ -395,8 +396,10 @@ int dx_upsample_bwd(const float* dxup, const float* xs, const float* mu, const f
   DX_REQUIRE(Dm == D && B > 0 && L > 0 && T > 0, "dx_upsample_bwd: bad dims (D must be 128)");
   UpBwdArgs a{dxup, xs, mu, sigma, weights, lens, dxs, dsigma, B, L, T};
   hipStream_t s = (hipStream_t)stream;
-  if (bwd_smem<64>(L) <= LDS_BUDGET) launch_bwd<64>(a, s);
-  else if (bwd_smem<32>(L) <= LDS_BUDGET) launch_bwd<32>(a, s);
+  // 32-frame tiles: 65 KB of LDS at L = 120, two workgroups per CU (64-frame tiles: 112 KB, one per CU, 153 vs 99 us)
+  static const int force_tt = getenv("DX_UP_TT") ? atoi(getenv("DX_UP_TT")) : 32;
+  if (force_tt == 64 && bwd_smem<64>(L) <= LDS_BUDGET) launch_bwd<64>(a, s);
+  else if (force_tt != 16 && bwd_smem<32>(L) <= LDS_BUDGET) launch_bwd<32>(a, s);
   else { DX_REQUIRE(bwd_smem<16>(L) <= LDS_BUDGET, "dx_upsample_bwd: L=%d too long for the LDS tiles", L); launch_bwd<16>(a, s); }
   DX_LAUNCH_CHECK("dx_upsample_bwd");
   return DX_OK;
