@@ -201,6 +201,32 @@ def test_deep_k_conv_path(ops, Cin, Cout, taps, x_bf16):
         ops.set_precision('f32')
 
 
+@pytest.mark.parametrize('Cin,Cout,taps', [(256, 128, 3), (128, 256, 1), (128, 128, 3)])
+def test_conv_tile_skipping_with_many_batch_rows(ops, Cin, Cout, taps):
+    """More batch rows than the kernels number live tiles for (1024): the deep-K and weight-stationary kernels fall back to the
+    plain tile order, and the bf16 weight gradient to per-row limits read from memory."""
+    ops.set_precision('bf16')
+    try:
+        B, N = 1100, 130
+        g = torch.Generator().manual_seed(5)
+        lens = torch.randint(1, N + 1, (B,), generator=g).to(torch.int32).to(DEV)
+        wshape = (Cout, Cin, 3) if taps == 3 else (Cout, Cin)
+        w = randn(*wshape, seed=1, scale=1.0 / math.sqrt(Cin * taps))
+        b = randn(Cout, seed=2, scale=0.1)
+        x = randn(B, N, Cin, seed=3).to(torch.bfloat16)
+        pack = ops.PackedWeight(w)
+        ref = ref_conv(x.float(), w, b, taps)
+        valid = (torch.arange(N, device=DEV)[None, :] < lens[:, None])[:, :, None]
+        y = ops.conv_gemm(x, pack, b, lens=lens, mask_rows=True, halo=0)
+        assert rel_err(y, ref * valid) < 1e-2 and torch.equal(y * ~valid, torch.zeros_like(y))
+        dy = (randn(B, N, Cout, seed=4) * valid).to(torch.bfloat16)
+        dw, db = ops.conv_wgrad(dy, x, pack, lens, 0)
+        dw_ref, db_ref = ops.conv_wgrad(dy, x, pack)
+        assert rel_err(dw, dw_ref) < 1e-4 and rel_err(db, db_ref) < 1e-4
+    finally:
+        ops.set_precision('f32')
+
+
 def ref_attention(qkv, lens, heads, keep=None, p=0.0):
     B, N, D3 = qkv.shape
     D = D3 // 3
