@@ -645,12 +645,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
       }
       float keep[4] = {1.f, 1.f, 1.f, 1.f};
       if (a.thresh) dx_dropout_scale4(a.seed, drop_index(bh, a.N, qrow, kbase + kt * 16 + g * 4), a.thresh, a.inv_keep, keep);
+      float p[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float p = __builtin_amdgcn_exp2f(s[e] - lse_q);
-        if (tail_tile && kbase + kt * 16 + g * 4 + e >= len) p = 0.f;    // only the last key tile can hold padding keys
-        s[e] = p * (dp[e] * keep[e] - delta_q);                           // x QSCALE: applied once to dQ at the end
+      for (int e = 0; e < 4; ++e) p[e] = __builtin_amdgcn_exp2f(s[e] - lse_q);
+      if (tail_tile) {                                    // wave-uniform: only the last key tile can hold padding keys
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (kbase + kt * 16 + g * 4 + e >= len) p[e] = 0.f;
       }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] = p[e] * (dp[e] * keep[e] - delta_q);   // x QSCALE: applied once to dQ at the end
       ds[kt] = s;
     }
     const bf16x8 d01 = pack_pair(ds[0], ds[1]), d23 = pack_pair(ds[2], ds[3]);
@@ -727,7 +731,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwd
       delta_r = (tid < 64 && qn < a.N) ? a.delta[(size_t)bh * a.N + qn] : 0.f;
     }
     f32x4 pd[4], ds[4];
-    const bool tail_q = qbase + 64 > len;
+    const bool tail_q = qbase + 64 > len, tail_k = k0 + 64 > len;
     // Dropout words: one 64-bit draw covers 4 consecutive keys of a query row.  Here a lane owns ONE key and 16 query rows, and
     // the four lanes of a quad (keys 4m .. 4m+3) need the same 16 words: each lane draws 4 of them (rows g*4 + its quad index)
     // and the quad shares them by DPP instead of every lane drawing all 16 (the draws were ~40 % of this kernel's VALU time).
@@ -762,14 +766,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwd
           keepv[e] = bits >= a.thresh ? a.inv_keep : 0.f;
         }
       }
+      float p[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) p[e] = __builtin_amdgcn_exp2f(s[e] - lse_s[qt * 16 + g * 4 + e]);
+      if (tail_k || tail_q) {                             // wave-uniform: padding keys / queries exist only in the last tiles
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (!key_valid || qbase + qt * 16 + g * 4 + e >= len) p[e] = 0.f;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int ql = qt * 16 + g * 4 + e, q = qbase + ql;
-        float p = __builtin_amdgcn_exp2f(s[e] - lse_s[ql]);
-        if (!key_valid || (tail_q && q >= len)) p = 0.f;                  // padding key, or padding query in the last query tile
+        const int ql = qt * 16 + g * 4 + e;
         const float keep = keepv[e];
-        pd[qt][e] = p * keep;
-        ds[qt][e] = p * (dp[e] * keep - delta_s[ql]);                     // x QSCALE: applied once to dK at the end
+        pd[qt][e] = p[e] * keep;
+        ds[qt][e] = p[e] * (dp[e] * keep - delta_s[ql]);                  // x QSCALE: applied once to dK at the end
       }
     }
     const bf16x8 p01 = pack_pair(pd[0], pd[1]), p23 = pack_pair(pd[2], pd[3]);
