@@ -1093,7 +1093,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 // ds_read_b64_tr_b16 (hardware transposed read: a 16-lane group reads a 4-token x 16-channel block and each lane
 // receives one channel column) -- no transposing store pass, no shuffles.
 // ------------------------------------------------------------------------------------------------
-constexpr int WB_BK = 64;      // tokens per K chunk
+// tokens per K chunk: 128 where the staging registers fit without spilling (both operands stored bf16, or k = 1) - half the
+// barriers and chunk bookkeeping per MFMA: k = 3 launches -2.4 %, k = 1 launches -8 %; 64 for fp32-stored operands with k = 3
+constexpr int wb_bk(int taps, bool dyh, bool xh) { return (taps == 1 || (dyh && xh)) ? 128 : 64; }
 constexpr int WB_LD = 144;     // LDS row stride in bf16 elements (288 B)
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -1127,6 +1129,7 @@ __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel
   // wave: 64 co x 32 ci -> 4 x 2 x TAPS MFMA tiles; waves = 2 (co) x CIW (ci).
   // The dY tile and the (halo-extended) X tile are staged once per 64-token chunk and shared by the taps.
   constexpr int PAD = (TAPS - 1) / 2;
+  constexpr int WB_BK = wb_bk(TAPS, DYH, XH);
   constexpr int NT = CIW * 128;
   constexpr int CI_T = CIW * 32;
   constexpr int XROWS = WB_BK + TAPS - 1;
@@ -1566,7 +1569,7 @@ int dx_conv_wgrad(const void* dY, int ldy, const void* X, int ldx, float* G,
     // slices are needed anyway (prenet 1024 x 1024: 308 -> 239 us); the 128-wide layers stay on the narrow form (59 vs 67 us)
     const bool wide = use_wide && (Cin % 128) == 0 && dx_cdiv(Cout, TILE) * dx_cdiv(Cin, 64) >= 64;
     const int tiles = dx_cdiv(Cout, TILE) * dx_cdiv(Cin, wide ? 128 : 64);
-    const int total_chunks = B * dx_cdiv(N, WB_BK);
+    const int total_chunks = B * dx_cdiv(N, wb_bk(taps, dy_bf16 != 0, x_bf16 != 0));
     // split-K partials are fp32 atomics (~1.3 TB/s chip-wide), so the split is sized by atomic traffic, not by "as many as fit";
     // per-kernel rocprof sweeps (r01-g build): k = 3 layers 192 / 256 / 320 / 384 blocks -> 50.0 / 47.6 / 48.8 / 50.2 us,
     // k = 1 layers 96 / 128 / 160 / 192 / 256 / 384 -> 24.9 / 20.9 / 19.5 / 18.8 / 19.5 / 22.1 us
