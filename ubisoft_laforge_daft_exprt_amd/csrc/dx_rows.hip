@@ -6,6 +6,7 @@
 //   * masked mean pooling (model.py:714), batched transposes, row L2-normalise (model.py:904), cross entropy (loss.py:85)
 // All HBM-bound: the roofline for each is bytes moved / 8 TB/s (see DESIGN.md for the per-kernel byte counts).
 #include "dx_common.h"
+#include <stdlib.h>
 #include <algorithm>
 
 namespace {
@@ -641,7 +642,7 @@ int dx_scalar_conv_wgrad(const float* dout, int ldd, const float* rowscale, cons
   DX_REQUIRE(dout && s0 && lens && dw0 && db0, "dx_scalar_conv_wgrad: null pointer");
   DX_REQUIRE(D == 128 && ldd >= 0, "dx_scalar_conv_wgrad: hidden dim must be 128");  // ldd == 0: one row broadcast
   DX_REQUIRE(!s1 || (dw1 && db1), "dx_scalar_conv_wgrad: second stream needs its gradient buffers");
-  const int rpb = std::max(64, dx_cdiv(N, 4));       // few, long blocks: the cost is the number of same-address atomics
+  const int rpb = 64;       // with the row halves folded in LDS, short blocks win again (N/2, N/4, N/8, 64 rows: 66 / 40 / 31 / 30 us)
   hipLaunchKernelGGL(scalar_conv_wgrad_kernel, dim3(dx_cdiv(N, rpb), B), dim3(256), 0, (hipStream_t)stream,
                      dout, ldd, rowscale, s0, s1, lens, dw0, db0, dw1, db1, B, N, rpb);
   DX_LAUNCH_CHECK("dx_scalar_conv_wgrad");
