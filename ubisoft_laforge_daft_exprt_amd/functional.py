@@ -56,6 +56,8 @@ class Lengths:
     """Valid lengths of one axis of a padded batch: int32 on the device for the kernels, Python ints for shapes."""
 
     def __init__(self, lengths: torch.Tensor, host=None):
+        if not lengths.is_cuda:
+            raise RuntimeError('lengths must live on the GPU (the kernels read them as device memory); got a CPU tensor')
         self.host = [int(v) for v in (lengths.tolist() if host is None else host)]  # one D2H sync unless given
         self.max = max(self.host)
         self.total = sum(self.host)

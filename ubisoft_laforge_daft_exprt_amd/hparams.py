@@ -51,6 +51,14 @@ class HyperParams:
         self.energy_consistency_weight = 0.05
         self.pitch_consistency_weight = 0.15
         self.pitch_predictor_path = ''
+        # optimiser / schedule (hparams.py:92-100; read by optim.FusedAdam, optim.update_learning_rate and train_steps.Trainer)
+        self.accumulation_steps = 1
+        self.betas = [0.9, 0.98]
+        self.epsilon = 1e-9
+        self.weight_decay = 1e-6
+        self.grad_clip_thresh = float('inf')
+        self.initial_learning_rate = 1e-4
+        self.max_learning_rate = 1e-3
         # gradient reversal strength (model.py:51; not defined by the reference defaults)
         self.lambda_reversal = 1.0
         # module shapes (hparams.py:106-127)

@@ -14,6 +14,24 @@ from . import ops
 from .functional import Lengths
 
 
+def pitch_predictor_shapes(n_mel_channels=80, hidden_dim=256, kernel_size=3):
+    """state-dict keys / shapes of the frozen PitchPredictor checkpoint (layers/pitch_predictor.py:38-74: three weight-normed
+    Conv1d + BatchNorm1d stages and a weight-normed Conv1d to one channel), for seeded synthetic weights."""
+    shapes = {}
+    dims = [(n_mel_channels, hidden_dim), (hidden_dim, hidden_dim), (hidden_dim, hidden_dim), (hidden_dim, 1)]
+    for i, (cin, cout) in enumerate(dims):
+        pre = f'conv_layers.{4 * i}.conv.'
+        shapes[pre + 'bias'] = (cout,)
+        shapes[pre + 'weight_g'] = (cout, 1, 1)
+        shapes[pre + 'weight_v'] = (cout, cin, kernel_size)
+        if i < 3:
+            bn = f'conv_layers.{4 * i + 2}.'
+            for name in ('weight', 'bias', 'running_mean', 'running_var'):
+                shapes[bn + name] = (cout,)
+            shapes[bn + 'num_batches_tracked'] = ()
+    return shapes
+
+
 def fold_pitch_predictor(state_dict, device):
     """Frozen PitchPredictor (layers/pitch_predictor.py:38-74) -> plain conv weights: weight_norm (w = g v / ||v||, norm over
     (in, k) per output channel) folded into the weight, eval-mode BatchNorm1d folded into a per-channel scale/shift."""
@@ -151,7 +169,7 @@ class DaftExprtLoss(nn.Module):
         mel_preds, output_lengths = decoder_preds
         if not mel_preds.is_cuda:
             raise RuntimeError('DaftExprtLoss (MI355X build) runs on the GPU only; there is no CPU path')
-        lens = output_lengths if isinstance(output_lengths, Lengths) else Lengths(output_lengths)
+        lens = output_lengths if isinstance(output_lengths, Lengths) else Lengths(output_lengths, host=getattr(output_lengths, '_dx_host_lengths', None))
         pm = post_multipliers if (self.post_mult_weight != 0.0 and torch.is_tensor(post_multipliers)) else None
         cfg = {'spk_weight': self.update_adversarial_weight(iteration), 'pmw': self.post_mult_weight, 'msw': self.mel_spec_weight,
                'ecw': self.energy_consistency_weight, 'pcw': self.pitch_consistency_weight if self.pitch_layers is not None else 0.0}

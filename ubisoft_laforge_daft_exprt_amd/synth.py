@@ -120,3 +120,26 @@ CONFIGS = {
     'C4': dict(batch_size=256, sym_len_range=(60, 100), seed=1238),
     'C5': dict(batch_size=8, sym_len_range=(400, 500), dur_range=(4, 12), seed=1239),
 }
+
+
+def synthetic_inference_batch(batch_size=256, sym_len_range=(60, 100), seed=1238, n_symbols=76, spk_dim=192, accent_dim=128,
+                              n_speakers=2):
+    """BASELINE.json config 4 (C4) inputs of ``DaftExprt.inference`` (reference model.py:1026-1114), CPU tensors:
+    (inputs 6-tuple, external_prosody dict, external_embeddings (B, 192), external_accent_emb (B, 128)).
+    Durations are seconds in [0.05, 0.14) per valid symbol (4-12 frames at hop 256 / 22050 Hz): T_max ~ 800 at L = 100."""
+    g = torch.Generator(device='cpu')
+    g.manual_seed(seed)
+    lo, hi = sym_len_range
+    lens = torch.randint(lo, hi + 1, (batch_size,), generator=g)
+    lens[0] = hi
+    lens, _ = torch.sort(lens, descending=True)
+    L = int(lens.max())
+    valid = torch.arange(L)[None, :] < lens[:, None]
+    symbols = torch.randint(1, n_symbols, (batch_size, L), generator=g) * valid
+    dur = (0.05 + 0.09 * torch.rand(batch_size, L, generator=g)) * valid
+    energy = torch.randn(batch_size, L, generator=g) * valid
+    pitch = torch.randn(batch_size, L, generator=g).masked_fill(torch.rand(batch_size, L, generator=g) < 0.25, 0.0) * valid
+    inputs = (symbols.long(), torch.ones(batch_size, L), torch.ones(batch_size, L), 0.5 * torch.ones(batch_size, L), lens.long(),
+              torch.randint(0, max(n_speakers - 1, 1), (batch_size,), generator=g).long())
+    prosody = {'duration_preds': dur, 'durations_int': torch.zeros(batch_size, L, dtype=torch.long), 'energy_preds': energy, 'pitch_preds': pitch}
+    return inputs, prosody, torch.randn(batch_size, spk_dim, generator=g), 0.3 * torch.randn(batch_size, accent_dim, generator=g)
