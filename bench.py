@@ -178,7 +178,8 @@ def main():
         if use_events and it == args.steps - 1:
             # HIP-event bracketing of every conv-GEMM launch costs ~8 % of a step, so only the LAST timed step carries it
             lib().dx_prof_enable(0, 512)
-            ops.record_launches(True)
+            model.runtime.record_launches(True)
+            crit.runtime.record_launches(True)
         last = step(args.warmup + it, it)
     torch.cuda.synchronize()
     if world > 1:
@@ -204,7 +205,7 @@ def main():
         import ctypes
         n, ms = ctypes.c_int(0), ctypes.c_double(0.0)
         lib().dx_prof_collect(0, ctypes.cast(ctypes.pointer(n), ctypes.c_void_p), ctypes.cast(ctypes.pointer(ms), ctypes.c_void_p))
-        log = ops.record_launches(False) or []
+        log = (model.runtime.record_launches(False) or []) + (crit.runtime.record_launches(False) or [])
         flops = conv_algorithmic_flops(log, {int(batch[9].max()): frames, int(batch[5].max()): symbols})
         if n.value > 0 and ms.value > 0:
             achieved = flops / (ms.value * 1e-3) / 1e12

@@ -314,11 +314,9 @@ def test_long_form_bf16_mode_runs_and_tracks_fp32(dx):
     inputs, _ = model.parse_batch(DEV, batch)
     with torch.no_grad():
         ref = model(inputs)[3][0]
-        dx.set_precision('bf16')
-        try:
-            got = model(inputs)[3][0]
-        finally:
-            dx.set_precision('f32')
+        model.set_precision('bf16')               # the model's own runtime: nothing process-global changes
+        got = model(inputs)[3][0]
+        assert dx.get_precision() == 'f32'
     assert torch.isfinite(got).all()
     l1 = valid_mel_l1(got.cpu().numpy(), ref.cpu().numpy(), batch[9])
     print('bf16-vs-f32 valid mel L1 (long form)', l1)

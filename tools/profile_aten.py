@@ -24,7 +24,7 @@ reducer = GradientReducer(model, bucket_mb=16.0, grad_sink=True)
 pkg.manual_seed(1234)
 
 def step(it):
-    ops.invalidate_packs(); ops.repack_all(); reducer.zero_grad()
+    model.runtime.invalidate_packs(); ops.repack_all(model.runtime); reducer.zero_grad()
     out = model(inputs); total, _ = crit(out, targets, it); total.backward(); reducer.finish()
 
 for it in range(3): step(it)

@@ -8,4 +8,4 @@ from .hparams import HyperParams  # noqa: F401
 from .model import DaftExprt  # noqa: F401
 from .loss import DaftExprtLoss  # noqa: F401
 from .functional import manual_seed  # noqa: F401
-from .ops import set_precision, get_precision  # noqa: F401
+from .ops import set_precision, get_precision, Runtime  # noqa: F401

@@ -2,6 +2,7 @@
 #include "dx_common.h"
 #include <stdarg.h>
 #include <string.h>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -13,6 +14,7 @@ struct ProfState {
   size_t used = 0;
 };
 ProfState g_prof[DX_PROF_NKINDS];
+std::mutex g_prof_mutex;   // launches come from the caller's thread AND from autograd engine threads (backward)
 }  // namespace
 
 extern "C" {
@@ -32,6 +34,7 @@ int dx_version(void) { return 1; }
 // capacity = maximum number of launches recorded between dx_prof_enable and dx_prof_collect.
 int dx_prof_enable(int kind, int capacity) {
   DX_REQUIRE(kind >= 0 && kind < DX_PROF_NKINDS && capacity > 0, "dx_prof_enable: bad arguments");
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   ProfState& p = g_prof[kind];
   while ((int)p.start.size() < capacity) {
     hipEvent_t a, b;
@@ -50,6 +53,7 @@ int dx_prof_enable(int kind, int capacity) {
 // Synchronises the recorded events and returns the number of launches and their summed duration (ms).
 int dx_prof_collect(int kind, int* launches, double* total_ms) {
   DX_REQUIRE(kind >= 0 && kind < DX_PROF_NKINDS && launches && total_ms, "dx_prof_collect: bad arguments");
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   ProfState& p = g_prof[kind];
   double sum = 0.0;
   for (size_t i = 0; i < p.used; ++i) {
@@ -66,11 +70,15 @@ int dx_prof_collect(int kind, int* launches, double* total_ms) {
 
 void dx_prof_begin(int kind, hipStream_t s) {
   ProfState& p = g_prof[kind];
+  if (!p.enabled) return;                      // the common case takes no lock
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   if (p.enabled && p.used < p.start.size()) hipEventRecord(p.start[p.used], s);
 }
 
 void dx_prof_end(int kind, hipStream_t s) {
   ProfState& p = g_prof[kind];
+  if (!p.enabled) return;
+  std::lock_guard<std::mutex> lock(g_prof_mutex);
   if (p.enabled && p.used < p.start.size()) {
     hipEventRecord(p.stop[p.used], s);
     ++p.used;

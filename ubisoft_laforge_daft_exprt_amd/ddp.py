@@ -5,27 +5,40 @@ exchange step of the path is the gradient all-reduce of 14.4 M fp32 values (57.5
 Utterances are independent units, so the forward/backward itself needs no collective.
 
 Design for one process per GPU on an 8-GPU xGMI mesh:
+  * like DistributedDataParallel, construction broadcasts rank 0's parameters (and buffers), so replicas that were initialised
+    with different seeds start identical
   * parameters are packed, in reverse registration order (~ the order autograd finishes them), into a few flat fp32
     buckets; ``param.grad`` is a VIEW into its bucket, so autograd accumulates straight into the communication buffer
   * a post-accumulate hook counts ready parameters; when a bucket is complete its all-reduce is issued asynchronously
     (``backend='nccl'`` is RCCL on ROCm) while the rest of backward keeps running on the compute stream
   * ``finish()`` waits for the outstanding collectives; averaging uses ReduceOp.AVG where the backend has it
+  * gradient accumulation over micro-batches (train.py:421-441): ``with reducer.accumulate(sync=is_last):`` around each
+    micro-batch's backward; only the last one launches collectives (one exchange of the accumulated sum instead of the
+    reference's one per micro-batch -- the average is the same)
 Few, large messages: with 7 point-to-point links per GPU the all-reduce is per-link bound, so 2-4 buckets of 16-32 MB
 amortise latency without delaying the first launch until the end of backward.
 """
 from __future__ import annotations
+
+import contextlib
 
 import torch
 import torch.distributed as dist
 
 
 class GradientReducer:
-    def __init__(self, module: torch.nn.Module, bucket_mb: float = 16.0, process_group=None, grad_sink: bool = False):
-        """``grad_sink=True``: the HIP backward kernels accumulate straight into the bucket views (functional.set_grad_sink);
-        requires ``zero_grad()`` of THIS object before every backward."""
+    def __init__(self, module: torch.nn.Module, bucket_mb: float = 16.0, process_group=None, grad_sink: bool = False,
+                 broadcast_parameters: bool = True):
+        """``grad_sink=True``: the HIP backward kernels accumulate straight into the bucket views (the model's ``runtime.sink``);
+        requires ``zero_grad()`` of THIS object before every step."""
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if self.world > 1 and broadcast_parameters:
+            src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
+            with torch.no_grad():
+                for t in list(module.parameters()) + list(module.buffers()):
+                    dist.broadcast(t.data, src=src, group=process_group)
         params = [p for p in module.parameters() if p.requires_grad]
         params.reverse()
         cap = int(bucket_mb * 1024 * 1024 / 4)
@@ -51,11 +64,14 @@ class GradientReducer:
             self.flat.append(flat)
         self.pending = [len(b) for b in self.buckets]
         self.works = []
+        self.sync = True
         self.hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
         self._avg = None
+        self.runtime = getattr(module, 'runtime', None) if grad_sink else None
         if grad_sink:
-            from . import functional
-            functional.set_grad_sink(True, self._on_grad)
+            if self.runtime is None:
+                raise ValueError('grad_sink=True needs a module with a ``runtime`` (ubisoft_laforge_daft_exprt_amd.DaftExprt)')
+            self.runtime.sink = True
 
     def _reduce_op(self):
         if self._avg is None:
@@ -66,7 +82,7 @@ class GradientReducer:
     def _on_grad(self, p):
         bi = self.bucket_of[p]
         self.pending[bi] -= 1
-        if self.pending[bi] == 0 and self.world > 1:
+        if self.pending[bi] == 0 and self.world > 1 and self.sync:
             op = self._reduce_op()
             work = dist.all_reduce(self.flat[bi], op=op, group=self.group, async_op=True)
             self.works.append((work, bi, op))
@@ -76,6 +92,23 @@ class GradientReducer:
         for flat in self.flat:
             flat.zero_()
         self.pending = [len(b) for b in self.buckets]
+
+    @contextlib.contextmanager
+    def accumulate(self, sync: bool = True):
+        """One micro-batch's backward inside a gradient-accumulation step.  ``sync=False``: its gradients are only summed
+        into the buckets; ``sync=True`` (the last micro-batch): completed buckets are all-reduced as usual."""
+        self._check_balanced()
+        self.pending = [len(b) for b in self.buckets]
+        self.sync = bool(sync)
+        try:
+            yield self
+        finally:
+            self.sync = True
+
+    def _check_balanced(self):
+        if any(n != 0 and n != len(b) for n, b in zip(self.pending, self.buckets)):
+            raise RuntimeError(f'gradient bookkeeping out of balance: pending per bucket = {self.pending} '
+                               '(a parameter received no gradient, or was counted twice)')
 
     def finish(self):
         """Call after backward: waits for the collectives; gradients are then averaged over ranks."""
@@ -92,6 +125,5 @@ class GradientReducer:
     def remove(self):
         for h in self.hooks:
             h.remove()
-        from . import functional
-        if functional._GRAD_SINK['hook'] == self._on_grad:
-            functional.set_grad_sink(False)
+        if self.runtime is not None:
+            self.runtime.sink = False

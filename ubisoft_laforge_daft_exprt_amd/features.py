@@ -107,12 +107,17 @@ def collate(batch, hparams, pin_memory=True):
 
 
 class FeatureSet:
-    """Utterance list sharded by rank (``DistributedSampler(shuffle=False)`` semantics: utterance i -> rank i mod world,
-    data_loader.py:310) and iterated in batches."""
+    """Utterance list sharded by rank with ``DistributedSampler(shuffle=False)`` semantics (data_loader.py:310): the list is
+    first padded BY REPETITION (wrapping around to its head) to a multiple of ``world``, then utterance i goes to rank i mod world,
+    so every rank owns the same number of utterances -- and therefore runs the same number of steps: a rank with one more batch
+    than its peers would block forever in the gradient all-reduce."""
 
     def __init__(self, list_file, hparams, batch_size, rank=0, world=1, return_raw_stats=False, drop_last=True):
         with open(list_file, 'r', encoding='utf-8') as f:
             rows = [line.strip().split('|') for line in f if line.strip()]
+        if world > 1 and rows and len(rows) % world:
+            pad = world - len(rows) % world
+            rows = rows + (rows * ((pad + len(rows) - 1) // len(rows)))[:pad]
         self.rows = rows[rank::world]
         self.hparams, self.batch_size, self.raw, self.drop_last = hparams, batch_size, return_raw_stats, drop_last
 

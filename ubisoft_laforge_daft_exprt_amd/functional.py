@@ -34,17 +34,10 @@ def next_seed() -> int:
 # autograd ``None``: no temporary gradient tensor, no ATen ``+=`` launch per parameter.  The autograd engine still runs the
 # parameter's post-accumulate hooks for an undefined gradient (torch 2.10), which is what drives the reducer's bucket
 # bookkeeping; GradientReducer.finish() raises if that ever stops being true.
+# The switch lives on the model's ops.Runtime (``rt.sink``); every Function captures it in ``ctx`` at forward time.
 # ----------------------------------------------------------------------------------------------------------------------
-_GRAD_SINK = {'enabled': False, 'hook': None}
-
-
-def set_grad_sink(enabled: bool, hook=None) -> None:
-    _GRAD_SINK['enabled'] = bool(enabled)
-    _GRAD_SINK['hook'] = hook if enabled else None
-
-
-def _sink(param):
-    if not _GRAD_SINK['enabled'] or param is None:
+def _sink(param, enabled):
+    if not enabled or param is None:
         return None
     g = param.grad
     if g is None or not g.is_contiguous() or g.dtype != torch.float32:
@@ -72,7 +65,8 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, pack, relu, grad_scale, lens, need_dx):
         x2 = x.reshape(-1, x.shape[-1]) if lens is None else x
-        y = ops.conv_gemm(x2, pack, bias, relu=relu, lens=lens, mask_rows=lens is not None)
+        ctx.prec = pack.rt.precision                       # captured: the backward runs in the mode of ITS forward
+        y = ops.conv_gemm(x2, pack, bias, relu=relu, lens=lens, mask_rows=lens is not None, prec=ctx.prec)
         ctx.save_for_backward(x2, y if relu else None)
         ctx.pack, ctx.relu, ctx.grad_scale, ctx.lens, ctx.need_dx, ctx.xshape = pack, relu, grad_scale, lens, need_dx, x.shape
         return y.view(*x.shape[:-1], y.shape[-1])
@@ -85,32 +79,37 @@ class LinearFn(torch.autograd.Function):
             dy = ops.mask_rows(dy, ctx.lens)
         if ctx.relu:
             dy = ops.relu_bwd(dy, y)
-        dw, db = ops.conv_wgrad(dy, x2, ctx.pack)
+        dw, db = ops.conv_wgrad(dy, x2, ctx.pack, prec=ctx.prec)
         dx = None
         if ctx.need_dx:
-            dx = ops.conv_gemm(dy, ctx.pack, None, transpose=True, out_scale=ctx.grad_scale).view(ctx.xshape)
+            dx = ops.conv_gemm(dy, ctx.pack, None, transpose=True, out_scale=ctx.grad_scale, prec=ctx.prec).view(ctx.xshape)
         return dx, dw, db, None, None, None, None, None
 
 
 class PaddedLinear:
     """Linear whose output width is not a multiple of 4 (speaker logits): the kernels see a zero-padded (Cout4, Cin) weight."""
 
-    def __init__(self, weight, bias):
+    def __init__(self, weight, bias, rt=None):
         self.weight, self.bias = weight, bias
+        self.rt = rt or ops.DEFAULT
         self.cout = weight.shape[0]
         self.cout4 = (self.cout + 3) // 4 * 4
         self._key = None
         self.wpad = self.bpad = self.pack = None
 
     def padded(self):
-        key = (self.weight._version, self.bias._version, self.weight.data_ptr())
+        # The key must see every way the parameter can change: autograd-visible writes (``_version``), re-homing of ``.data``
+        # (``data_ptr``: optim.FusedAdam moves parameters into flat buckets) and raw-pointer writes by ``dx_adam_step`` (the pack
+        # epoch, which the optimiser bumps after every step).
+        key = (self.weight._version, self.bias._version, self.weight.data_ptr(), self.bias.data_ptr(), self.rt.pack_epoch)
         if key != self._key:
             w = self.weight.detach()
-            self.wpad = torch.zeros(self.cout4, w.shape[1], dtype=w.dtype, device=w.device)
-            self.wpad[:self.cout].copy_(w)
-            self.bpad = torch.zeros(self.cout4, dtype=w.dtype, device=w.device)
+            if self.wpad is None or self.wpad.device != w.device:
+                self.wpad = torch.zeros(self.cout4, w.shape[1], dtype=w.dtype, device=w.device)
+                self.bpad = torch.zeros(self.cout4, dtype=w.dtype, device=w.device)
+                self.pack = ops.PackedWeight(self.wpad, self.rt)
+            self.wpad[:self.cout].copy_(w)                 # bumps wpad._version: the MFMA pack refreshes on its next use
             self.bpad[:self.cout].copy_(self.bias.detach())
-            self.pack = ops.PackedWeight(self.wpad)
             self._key = key
         return self.wpad, self.bpad, self.pack
 
@@ -119,7 +118,8 @@ class PaddedLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, padded: PaddedLinear):
         _, bpad, pack = padded.padded()
-        y = ops.conv_gemm(x, pack, bpad)
+        ctx.prec = pack.rt.precision
+        y = ops.conv_gemm(x, pack, bpad, prec=ctx.prec)
         ctx.save_for_backward(x)
         ctx.pack, ctx.cout = pack, padded.cout
         return y[:, :padded.cout].contiguous()
@@ -129,9 +129,9 @@ class PaddedLinearFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         dyp = torch.zeros(dy.shape[0], ctx.pack.cout, dtype=dy.dtype, device=dy.device)
         dyp[:, :ctx.cout].copy_(dy)
-        dw, db = ops.conv_wgrad(dyp, x, ctx.pack)
+        dw, db = ops.conv_wgrad(dyp, x, ctx.pack, prec=ctx.prec)
         dw, db = dw[:ctx.cout], db[:ctx.cout]
-        dx = ops.conv_gemm(dyp, ctx.pack, None, transpose=True)
+        dx = ops.conv_gemm(dyp, ctx.pack, None, transpose=True, prec=ctx.prec)
         return dx, dw, db, None
 
 
@@ -148,19 +148,23 @@ class FFTBlockFn(torch.autograd.Function):
         s_attn, s_ln1, s_ln2 = (next_seed(), next_seed(), next_seed()) if training else (0, 0, 0)
         film = film if film is None or film.stride(-1) == 1 else film.contiguous()
         L = lens.i32
-        qkv = ops.conv_gemm(x, packs['in'], in_b, lens=L, halo=0, out_dtype=ops.hidden_dtype())   # bf16 mode: attention reads bf16 q/k/v
-        att, lse = ops.attention_fwd(qkv, lens.i32, heads, s_attn, p_attn)
-        z1 = ops.conv_gemm(att, packs['out'], out_b, lens=L, halo=0)
-        sh = ops.gemm_shadow()                     # bf16 mode: GEMM operands also exist as bf16 copies written by their producers
+        rt = packs['in'].rt
+        prec = rt.precision                        # captured here, used by the backward (never re-read)
+        hd = ops.hidden_dtype(prec)
+        qkv = ops.conv_gemm(x, packs['in'], in_b, lens=L, halo=0, out_dtype=hd, prec=prec)   # bf16 mode: attention reads bf16 q/k/v
+        att, lse = ops.attention_fwd(qkv, lens.i32, heads, s_attn, p_attn, prec=prec)
+        z1 = ops.conv_gemm(att, packs['out'], out_b, lens=L, halo=0, prec=prec)
+        sh = ops.gemm_shadow(prec)                 # bf16 mode: GEMM operands also exist as bf16 copies written by their producers
         ln1 = ops.ln_fwd(z1, x, ln1_w, ln1_b, None, lens.i32, seed_pre=s_ln1, p_pre=p_attn, shadow=sh)
         y1, mean1, rstd1 = ln1[:3]
         y1g = ln1[3] if sh else y1                 # the copy the GEMMs read
-        h = ops.conv_gemm(y1g, packs['c1'], c1_b, relu=True, lens=L, halo=1, out_dtype=ops.hidden_dtype())   # conv2 reads one row past the end
-        z2 = ops.conv_gemm(h, packs['c2'], c2_b, lens=L, halo=0)
+        h = ops.conv_gemm(y1g, packs['c1'], c1_b, relu=True, lens=L, halo=1, out_dtype=hd, prec=prec)   # conv2 reads one row past the end
+        z2 = ops.conv_gemm(h, packs['c2'], c2_b, lens=L, halo=0, prec=prec)
         y2, mean2, rstd2 = ops.ln_fwd(z2, y1, ln2_w, ln2_b, film, lens.i32, seed_pre=s_ln2, p_pre=p_conv)
         ctx.save_for_backward(x, film, qkv, att, lse, z1, mean1, rstd1, y1g, h, z2, mean2, rstd2, ln1_w, ln1_b, ln2_w, ln2_b)
         ctx.lens, ctx.packs, ctx.heads = lens, packs, heads
         ctx.drop = (p_attn, p_conv, s_attn, s_ln1, s_ln2)
+        ctx.prec, ctx.sink = prec, rt.sink
         return y2
 
     @staticmethod
@@ -175,26 +179,27 @@ class FFTBlockFn(torch.autograd.Function):
         pad = ops.ZeroArena.padded
         arena = ops.ZeroArena(x.device, 6 * pad(D) + pad(B * 2 * D) + 2 * pad(3 * D * Fc) + pad(Fc) + pad(D * D) + pad(3 * D * D) + pad(3 * D) + 64)
         P = packs.get('params', {})
-        sk = {k: _sink(v) for k, v in P.items()}
+        prec = ctx.prec
+        sk = {k: _sink(v, ctx.sink) for k, v in P.items()}
         g = sk.get
-        sh = ops.gemm_shadow()
+        sh = ops.gemm_shadow(prec)
         r2 = ops.ln_bwd(dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, L, want_da=p_conv > 0, seed_pre=s_ln2,
                         p_pre=p_conv, arena=arena, w_sink=g('ln2_w'), b_sink=g('ln2_b'), shadow=sh)
         dz2, da2, dln2_w, dln2_b, dfilm = r2[:5]
         dff = r2[5] if sh else (da2 if da2 is not None else dz2)      # gradient w.r.t. the conv2 output, as the GEMMs read it
-        dc2_w, dc2_b = ops.conv_wgrad(dff, h, packs['c2'], L, 0, arena=arena, w_sink=g('c2_w'), b_sink=g('c2_b'))
-        dh = ops.conv_gemm(dff, packs['c2'], None, transpose=True, relu_aux=h, lens=L, halo=1, out_dtype=h.dtype)
-        dc1_w, dc1_b = ops.conv_wgrad(dh, y1, packs['c1'], L, 1, arena=arena, w_sink=g('c1_w'), b_sink=g('c1_b'))
-        dy1 = ops.conv_gemm(dh, packs['c1'], None, transpose=True, out=dz2, accumulate=True, lens=L, halo=0)  # + residual branch
+        dc2_w, dc2_b = ops.conv_wgrad(dff, h, packs['c2'], L, 0, arena=arena, w_sink=g('c2_w'), b_sink=g('c2_b'), prec=prec)
+        dh = ops.conv_gemm(dff, packs['c2'], None, transpose=True, relu_aux=h, lens=L, halo=1, out_dtype=h.dtype, prec=prec)
+        dc1_w, dc1_b = ops.conv_wgrad(dh, y1, packs['c1'], L, 1, arena=arena, w_sink=g('c1_w'), b_sink=g('c1_b'), prec=prec)
+        dy1 = ops.conv_gemm(dh, packs['c1'], None, transpose=True, out=dz2, accumulate=True, lens=L, halo=0, prec=prec)  # + residual branch
         r1 = ops.ln_bwd(dy1, z1, mean1, rstd1, ln1_w, ln1_b, None, L, want_da=p_attn > 0, seed_pre=s_ln1,
                         p_pre=p_attn, arena=arena, w_sink=g('ln1_w'), b_sink=g('ln1_b'), shadow=sh)
         dz1, da1, dln1_w, dln1_b = r1[:4]
         dproj = r1[5] if sh else (da1 if da1 is not None else dz1)
-        dout_w, dout_b = ops.conv_wgrad(dproj, att, packs['out'], L, 0, arena=arena, w_sink=g('out_w'), b_sink=g('out_b'))
-        datt = ops.conv_gemm(dproj, packs['out'], None, transpose=True, lens=L, halo=0)
-        dqkv = ops.attention_bwd(qkv, att, datt, lse, L, ctx.heads, s_attn, p_attn, out_dtype=qkv.dtype)
-        din_w, din_b = ops.conv_wgrad(dqkv, x, packs['in'], L, 0, arena=arena, w_sink=g('in_w'), b_sink=g('in_b'))
-        dx = ops.conv_gemm(dqkv, packs['in'], None, transpose=True, out=dz1, accumulate=True, lens=L, halo=0)  # + residual branch
+        dout_w, dout_b = ops.conv_wgrad(dproj, att, packs['out'], L, 0, arena=arena, w_sink=g('out_w'), b_sink=g('out_b'), prec=prec)
+        datt = ops.conv_gemm(dproj, packs['out'], None, transpose=True, lens=L, halo=0, prec=prec)
+        dqkv = ops.attention_bwd(qkv, att, datt, lse, L, ctx.heads, s_attn, p_attn, out_dtype=qkv.dtype, prec=prec)
+        din_w, din_b = ops.conv_wgrad(dqkv, x, packs['in'], L, 0, arena=arena, w_sink=g('in_w'), b_sink=g('in_b'), prec=prec)
+        dx = ops.conv_gemm(dqkv, packs['in'], None, transpose=True, out=dz1, accumulate=True, lens=L, halo=0, prec=prec)  # + residual branch
         return (dx, dfilm, None, None, None, None,
                 din_w, din_b, dout_w, dout_b, dln1_w, dln1_b, dc1_w, dc1_b, dc2_w, dc2_b, dln2_w, dln2_b)
 
@@ -210,18 +215,21 @@ class AccentFrontFn(torch.autograd.Function):
         seeds = [next_seed() if training else 0 for _ in range(3)]
         x0 = ops.transpose(mel.contiguous())                                   # (B, T, n_mel) channels-last
         L = lens.i32
-        hd = ops.hidden_dtype()                                               # 1024-wide tensors: bf16 in bf16 operand mode
-        h0 = ops.conv_gemm(x0, packs['p0'], c0_b, relu=True, lens=L, halo=2, out_dtype=hd)   # three stacked k=3 convs: halos 2, 1, 0
+        rt = packs['p0'].rt
+        prec = rt.precision
+        hd = ops.hidden_dtype(prec)                                           # 1024-wide tensors: bf16 in bf16 operand mode
+        h0 = ops.conv_gemm(x0, packs['p0'], c0_b, relu=True, lens=L, halo=2, out_dtype=hd, prec=prec)   # three stacked k=3 convs: halos 2, 1, 0
         y0, m0, r0 = ops.ln_fwd(h0, None, l0_w, l0_b, None, L, seed_post=seeds[0], p_post=p, halo=2)
-        h1 = ops.conv_gemm(y0, packs['p1'], c1_b, relu=True, lens=L, halo=1, out_dtype=hd)
+        h1 = ops.conv_gemm(y0, packs['p1'], c1_b, relu=True, lens=L, halo=1, out_dtype=hd, prec=prec)
         y1, m1, r1 = ops.ln_fwd(h1, None, l1_w, l1_b, None, L, seed_post=seeds[1], p_post=p, halo=1)
-        h2 = ops.conv_gemm(y1, packs['p2'], c2_b, relu=True, lens=L, halo=0)
+        h2 = ops.conv_gemm(y1, packs['p2'], c2_b, relu=True, lens=L, halo=0, prec=prec)
         y2, m2, r2 = ops.ln_fwd(h2, None, l2_w, l2_b, None, L, seed_post=seeds[2], p_post=p, halo=0)
         energy, pitch = energy.contiguous(), pitch.contiguous()
         out = ops.accent_sum(y2, energy, pitch, we, be, wp, bp, pe, lens.i32)
         ctx.save_for_backward(x0, h0, m0, r0, y0, h1, m1, r1, y1, h2, m2, r2, energy, pitch, l0_w, l0_b, l1_w, l1_b, l2_w, l2_b)
         ctx.lens, ctx.packs, ctx.p, ctx.seeds = lens, packs, p, seeds
         ctx.emb_params = (we, be, wp, bp)
+        ctx.prec, ctx.sink = prec, rt.sink
         return out
 
     @staticmethod
@@ -229,22 +237,23 @@ class AccentFrontFn(torch.autograd.Function):
         x0, h0, m0, r0, y0, h1, m1, r1, y1, h2, m2, r2, energy, pitch, l0_w, l0_b, l1_w, l1_b, l2_w, l2_b = ctx.saved_tensors
         lens, packs, p, seeds = ctx.lens, ctx.packs, ctx.p, ctx.seeds
         dout = ops.mask_rows(dout.contiguous(), lens.i32)
-        dwe, dbe, dwp, dbp = ops.scalar_conv_wgrad(dout, energy, pitch, lens.i32, sinks=tuple(_sink(q) for q in ctx.emb_params))
+        dwe, dbe, dwp, dbp = ops.scalar_conv_wgrad(dout, energy, pitch, lens.i32, sinks=tuple(_sink(q, ctx.sink) for q in ctx.emb_params))
         L = lens.i32
         P = packs.get('params', {})
-        sk = {k: _sink(v) for k, v in P.items()}
+        prec = ctx.prec
+        sk = {k: _sink(v, ctx.sink) for k, v in P.items()}
         g = sk.get
         dz2, _, dl2_w, dl2_b, _ = ops.ln_bwd(dout, h2, m2, r2, l2_w, l2_b, None, L, relu_mask=True, seed_post=seeds[2], p_post=p,
                                               w_sink=g('l2_w'), b_sink=g('l2_b'), halo=0)
-        dc2_w, dc2_b = ops.conv_wgrad(dz2, y1, packs['p2'], L, 0, w_sink=g('c2_w'), b_sink=g('c2_b'))
-        dy1 = ops.conv_gemm(dz2, packs['p2'], None, transpose=True, lens=L, halo=1, out_dtype=h1.dtype)
+        dc2_w, dc2_b = ops.conv_wgrad(dz2, y1, packs['p2'], L, 0, w_sink=g('c2_w'), b_sink=g('c2_b'), prec=prec)
+        dy1 = ops.conv_gemm(dz2, packs['p2'], None, transpose=True, lens=L, halo=1, out_dtype=h1.dtype, prec=prec)
         dz1, _, dl1_w, dl1_b, _ = ops.ln_bwd(dy1, h1, m1, r1, l1_w, l1_b, None, L, relu_mask=True, seed_post=seeds[1], p_post=p,
                                               w_sink=g('l1_w'), b_sink=g('l1_b'), halo=1)
-        dc1_w, dc1_b = ops.conv_wgrad(dz1, y0, packs['p1'], L, 1, w_sink=g('c1_w'), b_sink=g('c1_b'))
-        dy0 = ops.conv_gemm(dz1, packs['p1'], None, transpose=True, lens=L, halo=2, out_dtype=h0.dtype)
+        dc1_w, dc1_b = ops.conv_wgrad(dz1, y0, packs['p1'], L, 1, w_sink=g('c1_w'), b_sink=g('c1_b'), prec=prec)
+        dy0 = ops.conv_gemm(dz1, packs['p1'], None, transpose=True, lens=L, halo=2, out_dtype=h0.dtype, prec=prec)
         dz0, _, dl0_w, dl0_b, _ = ops.ln_bwd(dy0, h0, m0, r0, l0_w, l0_b, None, L, relu_mask=True, seed_post=seeds[0], p_post=p,
                                               w_sink=g('l0_w'), b_sink=g('l0_b'), halo=2)
-        dc0_w, dc0_b = ops.conv_wgrad(dz0, x0, packs['p0'], L, 2, w_sink=g('c0_w'), b_sink=g('c0_b'))
+        dc0_w, dc0_b = ops.conv_wgrad(dz0, x0, packs['p0'], L, 2, w_sink=g('c0_w'), b_sink=g('c0_b'), prec=prec)
         return (None, None, None, None, None, None, None, None,
                 dc0_w, dc0_b, dl0_w, dl0_b, dc1_w, dc1_b, dl1_w, dl1_b, dc2_w, dc2_b, dl2_w, dl2_b, dwe, dbe, dwp, dbp)
 
@@ -314,7 +323,7 @@ class AddPosFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------------------------------
 class GaussianUpsampleFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, enc, dur_float, dur_int, energy, pitch, lens, n_frames, wd, bd, we, be, wp, bp, wr, br):
+    def forward(ctx, enc, dur_float, dur_int, energy, pitch, lens, n_frames, rt, wd, bd, we, be, wp, bp, wr, br):
         dur_float, energy, pitch = dur_float.contiguous(), energy.contiguous(), pitch.contiguous()
         xs, z, sigma = ops.upsample_prep(enc.contiguous(), dur_float, energy, pitch, wd, bd, we, be, wp, bp, wr, br, lens.i32)
         mu, _totals = ops.duration_scan(dur_int.contiguous())
@@ -322,6 +331,7 @@ class GaussianUpsampleFn(torch.autograd.Function):
         ctx.save_for_backward(xs, z, sigma, mu, weights, dur_float, energy, pitch, wd, bd, wr)
         ctx.lens = lens
         ctx.params = (wd, bd, we, be, wp, bp, wr, br)
+        ctx.sink = bool(rt is not None and rt.sink)
         ctx.mark_non_differentiable(weights)
         return xup, weights
 
@@ -331,13 +341,14 @@ class GaussianUpsampleFn(torch.autograd.Function):
         lens = ctx.lens
         dxs, dsigma = ops.upsample_bwd(dxup.contiguous(), xs, mu, sigma, weights, lens.i32)
         pwd, pbd, pwe, pbe, pwp, pbp, pwr, pbr = ctx.params
-        swr = _sink(pwr)
+        sk = lambda q: _sink(q, ctx.sink)
+        swr = sk(pwr)
         dxs, dz, dwr, dbr = ops.upsample_sym_bwd(dxs, dsigma, xs, z, dur_float, lens.i32, wd, bd, wr,
-                                                 dwr_sink=None if swr is None else swr.view(-1), dbr_sink=_sink(pbr))
-        dwe, dbe, dwp, dbp = ops.scalar_conv_wgrad(dxs, energy, pitch, lens.i32, sinks=(_sink(pwe), _sink(pbe), _sink(pwp), _sink(pbp)))
-        dwd, dbd, _, _ = ops.scalar_conv_wgrad(wr.reshape(-1), dur_float, None, lens.i32, rowscale=dz, sinks=(_sink(pwd), _sink(pbd), None, None))
+                                                 dwr_sink=None if swr is None else swr.view(-1), dbr_sink=sk(pbr))
+        dwe, dbe, dwp, dbp = ops.scalar_conv_wgrad(dxs, energy, pitch, lens.i32, sinks=(sk(pwe), sk(pbe), sk(pwp), sk(pbp)))
+        dwd, dbd, _, _ = ops.scalar_conv_wgrad(wr.reshape(-1), dur_float, None, lens.i32, rowscale=dz, sinks=(sk(pwd), sk(pbd), None, None))
         denc = ops.mask_rows(dxs, lens.i32)  # the encoder output is zero-masked; rows >= len carry no gradient upstream
-        return (denc, None, None, None, None, None, None, dwd, dbd, dwe, dbe, dwp, dbp,
+        return (denc, None, None, None, None, None, None, None, dwd, dbd, dwe, dbe, dwp, dbp,
                 None if dwr is None else dwr.view(1, -1), dbr)
 
 
@@ -346,7 +357,8 @@ class MelProjectionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, pack, lens):
-        mel_cl = ops.conv_gemm(x, pack, bias, lens=lens.i32, mask_rows=True, halo=0)
+        ctx.prec = pack.rt.precision
+        mel_cl = ops.conv_gemm(x, pack, bias, lens=lens.i32, mask_rows=True, halo=0, prec=ctx.prec)
         ctx.save_for_backward(x)
         ctx.pack, ctx.lens = pack, lens
         return ops.transpose(mel_cl)
@@ -355,6 +367,6 @@ class MelProjectionFn(torch.autograd.Function):
     def backward(ctx, dmel):
         (x,) = ctx.saved_tensors
         d_cl = ops.mask_rows(ops.transpose(dmel.contiguous()), ctx.lens.i32)
-        dw, db = ops.conv_wgrad(d_cl, x, ctx.pack, ctx.lens.i32, 0)
-        dx = ops.conv_gemm(d_cl, ctx.pack, None, transpose=True, lens=ctx.lens.i32, halo=0)
+        dw, db = ops.conv_wgrad(d_cl, x, ctx.pack, ctx.lens.i32, 0, prec=ctx.prec)
+        dx = ops.conv_gemm(d_cl, ctx.pack, None, transpose=True, lens=ctx.lens.i32, halo=0, prec=ctx.prec)
         return dx, dw, db, None, None

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import torch
 
+from . import ops
 from .functional import Lengths
 
 
@@ -45,7 +46,6 @@ class GraphedSynthesizer:
     # -- device side -----------------------------------------------------------------------------------------------------
     def _device_forward(self, st):
         m = self.model
-        from . import ops
         spk = m.spk_projection(ops.l2_normalize(st['spk_embs']), need_dx=False)
         film = m.style_adapter(st['accent_emb'] + spk)
         in_lens = Lengths(st['in_lens'], host=st['in_host'])
@@ -87,6 +87,8 @@ class GraphedSynthesizer:
                     entry = (graph, static, outs)
                     self.graphs[key] = entry
                 graph, static, outs = entry
+                ops.repack_all(self.model.runtime)        # weights changed since capture (load_state_dict, an optimiser step)? one
+                                                          # launch rewrites the SAME pack buffers the captured kernels read
                 for k, v in live.items():
                     static[k].copy_(v)
                 graph.replay()

@@ -32,7 +32,7 @@ def pitch_predictor_shapes(n_mel_channels=80, hidden_dim=256, kernel_size=3):
     return shapes
 
 
-def fold_pitch_predictor(state_dict, device):
+def fold_pitch_predictor(state_dict, device, rt=None):
     """Frozen PitchPredictor (layers/pitch_predictor.py:38-74) -> plain conv weights: weight_norm (w = g v / ||v||, norm over
     (in, k) per output channel) folded into the weight, eval-mode BatchNorm1d folded into a per-channel scale/shift."""
     layers = []
@@ -63,7 +63,7 @@ def fold_pitch_predictor(state_dict, device):
     bpad[:1] = last['b']
     last['w'], last['b'] = wpad, bpad
     for layer in layers:
-        layer['pack'] = ops.PackedWeight(layer['w'])
+        layer['pack'] = ops.PackedWeight(layer['w'], rt)
     return layers
 
 
@@ -99,14 +99,15 @@ class _LossFn(torch.autograd.Function):
         if pitch_layers is not None and frames_pitch is not None and cfg['pcw'] > 0:
             # frozen predictor on the predicted mel, channels-last; gradient flows through it to the mel only
             x = ops.transpose(mel_pred)                                          # (B, T, M)
+            prec = pitch_layers[0]['pack'].rt.precision                          # one value for the whole chain
             acts = []
             depth = len(pitch_layers) - 1                                       # stacked k=3 convs: halos 3, 2, 1, 0
             for i, layer in enumerate(pitch_layers[:-1]):
-                r = ops.conv_gemm(x, layer['pack'], layer['b'], relu=True, lens=lens.i32, halo=depth - i)
+                r = ops.conv_gemm(x, layer['pack'], layer['b'], relu=True, lens=lens.i32, halo=depth - i, prec=prec)
                 acts.append(r)
                 x = ops.channel_affine(r, layer['scale'], layer['shift'])
             last = pitch_layers[-1]
-            pp = ops.conv_gemm(x, last['pack'], last['b'], lens=lens.i32, halo=0)[:, :, 0].contiguous()  # (B, T)
+            pp = ops.conv_gemm(x, last['pack'], last['b'], lens=lens.i32, halo=0, prec=prec)[:, :, 0].contiguous()  # (B, T)
             frames_pitch = frames_pitch.contiguous()
             psum = ops.pitch_mse(pp, frames_pitch, lens.i32)
             terms[6:7] = psum[0] / (psum[1] + 1e-5)
@@ -117,8 +118,8 @@ class _LossFn(torch.autograd.Function):
             for k in range(len(pitch_layers) - 1, 0, -1):
                 prev = pitch_layers[k - 1]
                 g = ops.conv_gemm(g, pitch_layers[k]['pack'], None, transpose=True, post_scale=prev['scale'], post_shift=prev['zeros'],
-                                  relu_aux=acts[k - 1], lens=lens.i32, halo=depth - k + 1)
-            d = ops.conv_gemm(g, pitch_layers[0]['pack'], None, transpose=True, lens=lens.i32, halo=0)
+                                  relu_aux=acts[k - 1], lens=lens.i32, halo=depth - k + 1, prec=prec)
+            d = ops.conv_gemm(g, pitch_layers[0]['pack'], None, transpose=True, lens=lens.i32, halo=0, prec=prec)
             dmel = dmel + ops.transpose(d)
         total = terms[0] + terms[2] + terms[3] + terms[4] + cfg['ecw'] * terms[5] + cfg['pcw'] * terms[6]
         ctx.save_for_backward(dmel, d_spk, d_pm)
@@ -144,6 +145,7 @@ class DaftExprtLoss(nn.Module):
         self.energy_consistency_weight = getattr(hparams, 'energy_consistency_weight', 0.0)
         self.pitch_consistency_weight = getattr(hparams, 'pitch_consistency_weight', 0.0)
         self.pitch_layers = None
+        self.runtime = ops.Runtime(ops.DEFAULT.precision)     # this object's own execution state (see ops.Runtime)
         pp_path = getattr(hparams, 'pitch_predictor_path', '')
         if self.pitch_consistency_weight > 0 and pp_path:
             state = torch.load(pp_path, map_location='cpu', weights_only=True)
@@ -151,7 +153,11 @@ class DaftExprtLoss(nn.Module):
 
     def load_pitch_predictor(self, state_dict):
         """Frozen predictor from an in-memory state dict (same keys as layers/pitch_predictor.py)."""
-        self.pitch_layers = fold_pitch_predictor(state_dict, self.device)
+        self.pitch_layers = fold_pitch_predictor(state_dict, self.device, self.runtime)
+
+    def set_precision(self, name: str):
+        self.runtime.set_precision(name)
+        return self
 
     def update_adversarial_weight(self, iteration):
         """loss.py:52-55"""

@@ -43,8 +43,9 @@ class _Affine(nn.Module):
 
     @property
     def pack(self):
-        if self._pack is None or self._pack.weight is not self.weight:
-            self._pack = ops.PackedWeight(self.weight)
+        rt = getattr(self, '_dx_rt', None) or ops.DEFAULT
+        if self._pack is None or self._pack.weight is not self.weight or self._pack.rt is not rt:
+            self._pack = ops.PackedWeight(self.weight, rt)
         return self._pack
 
 
@@ -81,8 +82,9 @@ class _MHAParams(nn.Module):
 
     @property
     def in_pack(self):
-        if self._pack is None or self._pack.weight is not self.in_proj_weight:
-            self._pack = ops.PackedWeight(self.in_proj_weight)
+        rt = getattr(self, '_dx_rt', None) or ops.DEFAULT
+        if self._pack is None or self._pack.weight is not self.in_proj_weight or self._pack.rt is not rt:
+            self._pack = ops.PackedWeight(self.in_proj_weight, rt)
         return self._pack
 
 
@@ -200,8 +202,9 @@ class SpeakerClassifier(nn.Module):
         h = self.classifier[1](x, relu=True, grad_scale=-float(self.lambda_))   # GRL folded into the first input gradient
         h = self.classifier[3](h, relu=True)
         last = self.classifier[5].linear_layer
-        if self._padded is None or self._padded.weight is not last.weight:
-            self._padded = Fx.PaddedLinear(last.weight, last.bias)
+        rt = getattr(self, '_dx_rt', None) or ops.DEFAULT
+        if self._padded is None or self._padded.weight is not last.weight or self._padded.rt is not rt:
+            self._padded = Fx.PaddedLinear(last.weight, last.bias, rt)
         return Fx.PaddedLinearFn.apply(h, last.weight, last.bias, self._padded)
 
 
@@ -321,7 +324,7 @@ class GaussianUpsamplingModule(nn.Module):
             n_frames = int(durations_int.sum(dim=1).max())      # reference: torch.max(cumsum), model.py:497 (host sync)
         d, e, p, r = self.duration_projection.conv, self.energy_projection.conv, self.pitch_projection.conv, self.projection[0].linear_layer
         return Fx.GaussianUpsampleFn.apply(x, durations_float, durations_int, energies, pitch, lens, n_frames,
-                                           d.weight, d.bias, e.weight, e.bias, p.weight, p.bias, r.weight, r.bias)
+                                           getattr(self, '_dx_rt', None), d.weight, d.bias, e.weight, e.bias, p.weight, p.bias, r.weight, r.bias)
 
 
 class FrameDecoder(nn.Module):
@@ -361,6 +364,16 @@ class DaftExprt(nn.Module):
         self.gaussian_upsampling = GaussianUpsamplingModule(hparams)
         self.frame_decoder = FrameDecoder(hparams, is_training=is_training)
         self.spk_projection = LinearNorm(getattr(hparams, 'external_emb_dim', 192), self.hidden_embed_dim)
+        # execution state of THIS model (operand precision, pack epoch, gradient sink): shared by all of its sub-modules, read
+        # by nobody else.  It starts from the package default (``set_precision``) and is switched with ``model.set_precision``.
+        self.runtime = ops.Runtime(ops.DEFAULT.precision)
+        for m in self.modules():
+            m._dx_rt = self.runtime
+
+    def set_precision(self, name: str):
+        """'f32' (exact-f32 MFMA operands, parity mode) or 'bf16' (bf16 MFMA operands, fp32 accumulate; throughput mode)."""
+        self.runtime.set_precision(name)
+        return self
 
     # -- batch plumbing ------------------------------------------------------------------------------------------------
     def parse_batch(self, device, batch):

@@ -11,32 +11,75 @@ import torch
 
 from ._lib import lib
 
-_PRECISION = {'bf16': 0}
-_PACK_EPOCH = [0]
-_LAUNCH_LOG = [None]
+PRECISIONS = ('f32', 'bf16')
 
 
-def invalidate_packs() -> None:
-    """Forces every PackedWeight to re-pack on next use (what an optimiser step does by bumping parameter versions)."""
-    _PACK_EPOCH[0] += 1
+class Runtime:
+    """Execution state of ONE model (or one loss object): operand precision, the pack epoch its optimiser bumps, its gradient
+    sink and its launch log.  Nothing on the product path reads process-global mutable state: autograd Functions capture
+    ``runtime.precision`` / ``runtime.sink`` in ``ctx`` at forward time and use the captured values in backward, so two models
+    with different settings (or a precision flipped between a forward and its backward) cannot mix modes; backward runs on
+    autograd engine threads and only touches the ``ctx`` it was given (threading row)."""
+
+    def __init__(self, precision='f32'):
+        self.precision = _check_precision(precision)
+        self.pack_epoch = 0          # "an optimiser wrote the parameters through raw pointers" (optim.FusedAdam)
+        self.sink = False            # backward kernels accumulate straight into pre-zeroed ``param.grad`` (ddp.GradientReducer)
+        self.launch_log = None       # bench.py: (kind, ...) records of every launch, to price algorithmic FLOPs / bytes
+        self._packs = []             # weak refs to this runtime's PackedWeight objects (one-launch batched re-pack)
+        self._tables = {}
+
+    def set_precision(self, name):
+        self.precision = _check_precision(name)
+
+    def __deepcopy__(self, memo):
+        new = Runtime(self.precision)          # a copied model gets its own state; packs re-register as they are copied
+        new.pack_epoch = self.pack_epoch
+        memo[id(self)] = new
+        return new
+
+    def invalidate_packs(self):
+        self.pack_epoch += 1
+
+    def record_launches(self, enable: bool):
+        log = self.launch_log
+        self.launch_log = [] if enable else None
+        return log
 
 
-def record_launches(enable: bool):
-    """bench.py: collect (kind, rows, N, Cin, Cout, taps) of every GEMM launch to price algorithmic FLOPs."""
-    log = _LAUNCH_LOG[0]
-    _LAUNCH_LOG[0] = [] if enable else None
-    return log
+def _check_precision(name):
+    if name not in PRECISIONS:
+        raise ValueError(f"precision must be one of {PRECISIONS}, got {name!r}")
+    return name
+
+
+# Default runtime: the configuration that kernel-level calls without a model use (tests, micro-benchmarks) and whose
+# precision newly constructed models / losses START from.  A model never reads it after construction.
+DEFAULT = Runtime('f32')
 
 
 def set_precision(name: str) -> None:
-    """'f32': exact-f32 MFMA operands (parity mode).  'bf16': bf16 MFMA operands, fp32 accumulate (throughput mode)."""
-    if name not in ('f32', 'bf16'):
-        raise ValueError(f"precision must be 'f32' or 'bf16', got {name!r}")
-    _PRECISION['bf16'] = 1 if name == 'bf16' else 0
+    """'f32': exact-f32 MFMA operands (parity mode).  'bf16': bf16 MFMA operands, fp32 accumulate (throughput mode).
+    Sets the default for models / losses constructed afterwards (and for kernel-level calls without a model); a live model is
+    switched with ``model.set_precision(name)``."""
+    DEFAULT.set_precision(name)
 
 
 def get_precision() -> str:
-    return 'bf16' if _PRECISION['bf16'] else 'f32'
+    return DEFAULT.precision
+
+
+def invalidate_packs(rt=None) -> None:
+    (rt or DEFAULT).invalidate_packs()
+
+
+def record_launches(enable: bool, rt=None):
+    return (rt or DEFAULT).record_launches(enable)
+
+
+def _half(prec) -> int:
+    """operand-mode flag of the C ABI: 0 = exact f32, 1 = bf16 operands"""
+    return 1 if prec == 'bf16' else 0
 
 
 def _p(t):
@@ -57,9 +100,9 @@ def _is_bf16(t):
     return int(t is not None and t.dtype == torch.bfloat16)
 
 
-def hidden_dtype():
+def hidden_dtype(prec=None):
     """Storage type of the 1024-wide hidden activations: bf16 in bf16 operand mode (their HBM traffic bounds the step)."""
-    return torch.bfloat16 if _PRECISION['bf16'] else torch.float32
+    return torch.bfloat16 if _half(prec or DEFAULT.precision) else torch.float32
 
 
 def _rows(t):
@@ -72,91 +115,116 @@ def _rows(t):
     return ld
 
 
-_PACK_TABLES = {}
-_ALL_PACKS = []      # weak registry of every PackedWeight (for the one-launch batched re-pack)
-
-
-def repack_all(packs=None) -> int:
-    """Re-packs every stale PackedWeight with ONE kernel launch (after an optimiser step); returns the number packed."""
+def repack_all(rt=None, packs=None) -> int:
+    """Re-packs every stale PackedWeight of the runtime (at its current precision) with ONE kernel launch - what follows an
+    optimiser step; returns the number packed."""
     import struct
-    import weakref  # noqa: F401
-    live = [r() for r in _ALL_PACKS] if packs is None else list(packs)
+    rt = rt or DEFAULT
+    prec = rt.precision
+    live = [r() for r in rt._packs] if packs is None else list(packs)
     stale = []
     for pk in live:
         if pk is None or not pk.weight.is_cuda:
             continue
-        if pk._current_key() != pk._key:
-            pk._ensure_buffers()
-            stale.append(pk)
+        img = pk._image(prec)
+        if pk._current_key() != img.key:
+            stale.append((pk, img))
     if not stale:
         return 0
-    bf16 = _PRECISION['bf16']
-    sig = tuple((pk.weight.data_ptr(), pk.fwd.data_ptr(), pk.bwd.data_ptr()) for pk in stale)
-    table = _PACK_TABLES.get(sig)
+    sig = (prec,) + tuple((pk.weight.data_ptr(), img.fwd.data_ptr(), img.bwd.data_ptr()) for pk, img in stale)
+    table = rt._tables.get(sig)
     if table is None:                      # the descriptor table only changes when buffers are (re)allocated: upload it once
-        recs = b''.join(struct.pack('<QQQ8i', pk.weight.data_ptr(), pk.fwd.data_ptr(), pk.bwd.data_ptr(), pk.cout, pk.cin, pk.taps,
-                                     pk.dims[0], pk.dims[1], pk.dims[2], pk.dims[3], 0) for pk in stale)
-        table = torch.frombuffer(bytearray(recs), dtype=torch.uint8).to(stale[0].weight.device)
-        if len(_PACK_TABLES) > 8:
-            _PACK_TABLES.clear()
-        _PACK_TABLES[sig] = table
-    lib().dx_pack_weights_batched(_p(table), len(stale), bf16, _stream())
-    for pk in stale:
-        pk.bf16 = bf16
-        pk._key = pk._current_key()
+        recs = b''.join(struct.pack('<QQQ8i', pk.weight.data_ptr(), img.fwd.data_ptr(), img.bwd.data_ptr(), pk.cout, pk.cin, pk.taps,
+                                     img.dims[0], img.dims[1], img.dims[2], img.dims[3], 0) for pk, img in stale)
+        table = torch.frombuffer(bytearray(recs), dtype=torch.uint8).to(stale[0][0].weight.device)
+        if len(rt._tables) > 8:
+            rt._tables.clear()
+        rt._tables[sig] = table
+    lib().dx_pack_weights_batched(_p(table), len(stale), _half(prec), _stream())
+    for pk, img in stale:
+        img.key = pk._current_key()
     return len(stale)
 
 
-class PackedWeight:
-    """MFMA-ready copies of one (Cout, Cin[, taps]) parameter, refreshed when the parameter (or the precision) changes."""
+class _PackImage:
+    """The MFMA-ready copies of one parameter at one operand precision."""
+    __slots__ = ('fwd', 'bwd', 'dims', 'key', 'half')
 
-    def __init__(self, weight: torch.Tensor):
+    def __init__(self):
+        self.fwd = self.bwd = self.dims = self.key = None
+        self.half = 0
+
+
+class PackedWeight:
+    """MFMA-ready copies of one (Cout, Cin[, taps]) parameter, one image per operand precision in use, each refreshed when the
+    parameter changes.  Belongs to a Runtime (``rt``): its precision is the default for calls that do not name one, and its
+    pack epoch tells the images that an optimiser rewrote the parameter through raw pointers."""
+
+    def __init__(self, weight: torch.Tensor, rt: Runtime = None):
         import weakref
         self.weight = weight
+        self.rt = rt or DEFAULT
         self.cout, self.cin = weight.shape[0], weight.shape[1]
         self.taps = weight.shape[2] if weight.dim() == 3 else 1
-        self._key = None
-        self.fwd = self.bwd = None
-        self.bf16 = 0
-        self.dims = None
-        _ALL_PACKS.append(weakref.ref(self))
-        if len(_ALL_PACKS) > 4096:
-            _ALL_PACKS[:] = [r for r in _ALL_PACKS if r() is not None]
+        self._images = {}
+        self.rt._packs.append(weakref.ref(self))
+        if len(self.rt._packs) > 4096:
+            self.rt._packs[:] = [r for r in self.rt._packs if r() is not None]
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = PackedWeight(copy.deepcopy(self.weight, memo), copy.deepcopy(self.rt, memo))
+        memo[id(self)] = new
+        return new
 
     def _current_key(self):
         w = self.weight
         # the pack epoch stands for "an optimiser step happened": frozen weights (the pitch predictor of the loss) are not part of it
-        return (w._version, w.data_ptr(), _PRECISION['bf16'], _PACK_EPOCH[0] if w.requires_grad else 0)
+        return (w._version, w.data_ptr(), self.rt.pack_epoch if w.requires_grad else 0)
 
-    def _ensure_buffers(self):
+    def _image(self, prec) -> _PackImage:
+        img = self._images.get(prec)
         w = self.weight
-        bf16 = _PRECISION['bf16']
-        dt = torch.bfloat16 if bf16 else torch.float32
-        if self.fwd is None or self.fwd.dtype != dt or self.fwd.device != w.device:
+        if img is None or img.fwd.device != w.device:
+            img = _PackImage()
+            img.half = _half(prec)
+            dt = torch.bfloat16 if img.half else torch.float32
             dims = (ctypes.c_int * 4)()
-            lib().dx_pack_dims(self.cout, self.cin, bf16, ctypes.cast(dims, ctypes.c_void_p))
-            self.dims = [int(d) for d in dims]
-            self.fwd = torch.empty(self.taps * self.dims[0] * self.dims[1], dtype=dt, device=w.device)
-            self.bwd = torch.empty(self.taps * self.dims[2] * self.dims[3], dtype=dt, device=w.device)
+            lib().dx_pack_dims(self.cout, self.cin, img.half, ctypes.cast(dims, ctypes.c_void_p))
+            img.dims = [int(d) for d in dims]
+            img.fwd = torch.empty(self.taps * img.dims[0] * img.dims[1], dtype=dt, device=w.device)
+            img.bwd = torch.empty(self.taps * img.dims[2] * img.dims[3], dtype=dt, device=w.device)
+            self._images[prec] = img
+        return img
 
-    def refresh(self):
+    def image(self, prec=None) -> _PackImage:
+        """The up-to-date image at ``prec`` (default: the runtime's precision)."""
+        prec = prec or self.rt.precision
+        img = self._image(prec)
         key = self._current_key()
-        if key == self._key:
-            return self
-        self._ensure_buffers()
-        bf16 = _PRECISION['bf16']
-        lib().dx_pack_weights(_p(self.weight.detach()), _p(self.fwd), _p(self.bwd), self.cout, self.cin, self.taps, bf16, _stream())
-        self.bf16 = bf16
-        self._key = key
+        if key != img.key:
+            lib().dx_pack_weights(_p(self.weight.detach()), _p(img.fwd), _p(img.bwd), self.cout, self.cin, self.taps, img.half, _stream())
+            img.key = key
+        return img
+
+    def refresh(self, prec=None):
+        self.image(prec)
         return self
+
+
+def _log(pack_or_rt, rec):
+    rt = pack_or_rt.rt if isinstance(pack_or_rt, PackedWeight) else (pack_or_rt or DEFAULT)
+    if rt.launch_log is not None:
+        rt.launch_log.append(rec)
 
 
 def conv_gemm(x, pack: PackedWeight, bias=None, *, transpose=False, relu=False, post_scale=None, post_shift=None,
               relu_aux=None, out=None, accumulate=False, lens=None, mask_rows=False, out_scale=1.0, B=None, N=None, halo=-1,
-              out_dtype=torch.float32):
-    """y = epilogue(conv(x)).  ``transpose=True`` runs the input-gradient convolution (x is dY, result is dX)."""
+              out_dtype=torch.float32, prec=None):
+    """y = epilogue(conv(x)).  ``transpose=True`` runs the input-gradient convolution (x is dY, result is dX).
+    ``prec``: operand precision (default: the pack's runtime); backward passes hand in the precision their forward captured."""
     _chk(x, 'x')
-    pack.refresh()
+    img = pack.image(prec)
     if x.dim() == 2:
         B_, N_ = (1, x.shape[0]) if B is None else (B, N)
     else:
@@ -168,10 +236,9 @@ def conv_gemm(x, pack: PackedWeight, bias=None, *, transpose=False, relu=False, 
     if out is None:
         out = torch.empty(*x.shape[:-1], cout, dtype=out_dtype, device=x.device)
     ldy = _rows(out)
-    if _LAUNCH_LOG[0] is not None:
-        _LAUNCH_LOG[0].append(('conv', B_ * N_, N_, cin, cout, pack.taps))
-    lib().dx_conv_gemm(_p(x), ldx, _p(pack.bwd if transpose else pack.fwd), _p(bias), _p(out), ldy, B_, N_, cin, cout, pack.taps,
-                       pack.bf16, int(relu), _p(post_scale), _p(post_shift), _p(relu_aux),
+    _log(pack, ('conv', B_ * N_, N_, cin, cout, pack.taps))
+    lib().dx_conv_gemm(_p(x), ldx, _p(img.bwd if transpose else img.fwd), _p(bias), _p(out), ldy, B_, N_, cin, cout, pack.taps,
+                       img.half, int(relu), _p(post_scale), _p(post_shift), _p(relu_aux),
                        0 if relu_aux is None else _rows(relu_aux), int(accumulate), _p(lens), int(mask_rows), float(out_scale), int(halo),
                        _is_bf16(x), _is_bf16(out), _is_bf16(relu_aux), _stream())
     return out
@@ -204,7 +271,7 @@ def _zeros(arena, *shape, device=None):
     return arena.take(*shape) if arena is not None else torch.zeros(*shape, dtype=torch.float32, device=device)
 
 
-def conv_wgrad(dy, x, pack: PackedWeight, lens=None, halo=-1, bias=True, arena=None, w_sink=None, b_sink=None):
+def conv_wgrad(dy, x, pack: PackedWeight, lens=None, halo=-1, bias=True, arena=None, w_sink=None, b_sink=None, prec=None):
     """(dW, db): gradient w.r.t. the (Cout, Cin[, taps]) parameter in its own layout, and the bias gradient (column sums of
     dY, accumulated by the same launch).  ``w_sink`` / ``b_sink``: pre-zeroed ``.grad`` tensors to accumulate into directly
     (the corresponding return value is then None)."""
@@ -212,10 +279,9 @@ def conv_wgrad(dy, x, pack: PackedWeight, lens=None, halo=-1, bias=True, arena=N
     direct = w_sink is not None and pack.taps == 1          # Linear: G has the parameter's own layout
     g = w_sink.view(-1) if direct else _zeros(arena, pack.taps * pack.cout * pack.cin, device=x.device)
     db = b_sink if b_sink is not None else (_zeros(arena, pack.cout, device=x.device) if bias else None)
-    if _LAUNCH_LOG[0] is not None:
-        _LAUNCH_LOG[0].append(('wgrad', B_ * N_, N_, pack.cin, pack.cout, pack.taps))
+    _log(pack, ('wgrad', B_ * N_, N_, pack.cin, pack.cout, pack.taps))
     lib().dx_conv_wgrad(_p(dy), _rows(dy), _p(x), _rows(x), _p(g), B_, N_, pack.cin, pack.cout, pack.taps, _p(lens), int(halo),
-                        _PRECISION['bf16'], _is_bf16(dy), _is_bf16(x), _p(db), _stream())
+                        _half(prec or pack.rt.precision), _is_bf16(dy), _is_bf16(x), _p(db), _stream())
     db_ret = None if b_sink is not None else db
     if direct:
         return None, db_ret
@@ -237,29 +303,29 @@ def colsum(x, C=None):
     return out
 
 
-def attention_fwd(qkv, lens, heads, seed, p_drop):
+def attention_fwd(qkv, lens, heads, seed, p_drop, prec=None):
     B, N, D3 = qkv.shape
     D = D3 // 3
     ctx = torch.empty(B, N, D, dtype=torch.float32, device=qkv.device)
     lse = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device)
-    lib().dx_attention_fwd(_p(qkv), _rows(qkv), _p(lens), _p(ctx), D, _p(lse), B, N, heads, D, seed, float(p_drop), _PRECISION['bf16'],
+    lib().dx_attention_fwd(_p(qkv), _rows(qkv), _p(lens), _p(ctx), D, _p(lse), B, N, heads, D, seed, float(p_drop), _half(prec or DEFAULT.precision),
                            _is_bf16(qkv), _stream())
     return ctx, lse
 
 
-def attention_bwd(qkv, ctx, dctx, lse, lens, heads, seed, p_drop, out_dtype=torch.float32):
+def attention_bwd(qkv, ctx, dctx, lse, lens, heads, seed, p_drop, out_dtype=torch.float32, prec=None):
     B, N, D3 = qkv.shape
     D = D3 // 3
     dqkv = torch.empty(B, N, D3, dtype=out_dtype, device=qkv.device)
     delta = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device)
     lib().dx_attention_bwd(_p(qkv), _rows(qkv), _p(ctx), _p(dctx), _rows(dctx), _p(lse), _p(delta), _p(lens), _p(dqkv), _rows(dqkv),
-                           B, N, heads, D, seed, float(p_drop), _PRECISION['bf16'], _is_bf16(qkv), _is_bf16(dqkv), _stream())
+                           B, N, heads, D, seed, float(p_drop), _half(prec or DEFAULT.precision), _is_bf16(qkv), _is_bf16(dqkv), _stream())
     return dqkv
 
 
-def gemm_shadow():
+def gemm_shadow(prec=None):
     """True when producers should also emit a bf16 copy of a 128-wide fp32 tensor that the next GEMM consumes (bf16 operand mode)."""
-    return bool(_PRECISION['bf16'])
+    return bool(_half(prec or DEFAULT.precision))
 
 
 def ln_fwd(a, res, w, b, film, lens, *, seed_pre=0, p_pre=0.0, seed_post=0, p_post=0.0, halo=0, shadow=False):

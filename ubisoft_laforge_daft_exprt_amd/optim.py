@@ -4,10 +4,12 @@ Reference behaviour: ``Adam(betas=[0.9, 0.98], eps=1e-9, weight_decay=1e-6, amsg
 ``clip_grad_norm_(model.parameters(), grad_clip_thresh)`` (:443), linear warm-up then inverse-sqrt decay (:148-160).
 Parameters, gradients and both moments live in flat buckets (the gradient buckets are ddp.GradientReducer's communication
 buffers), so one ``dx_adam_step`` launch per bucket replaces ~10 ATen launches per parameter tensor.
+
+``state_dict()`` / ``load_state_dict()`` speak the ``torch.optim.Adam`` layout that the reference stores under the checkpoint's
+``'optimizer'`` key (train.py:80-85, :134-138): ``{'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [{..., 'params':
+[0..n-1]}]}`` with ``i`` indexing ``filter(requires_grad, model.parameters())``, so optimiser resume is drop-in in both directions.
 """
 from __future__ import annotations
-
-import math
 
 import torch
 
@@ -29,19 +31,30 @@ class FusedAdam:
         self.reducer = reducer
         self.lr, self.betas, self.eps, self.weight_decay, self.max_norm = lr, tuple(betas), eps, weight_decay, grad_clip_thresh
         self.step_count = 0
+        self.runtime = getattr(reducer.module, 'runtime', None) or ops.DEFAULT
         self.pflat, self.m, self.v = [], [], []
-        for bucket, gflat in zip(reducer.buckets, reducer.flat):
+        self._slot = {}                                # parameter -> (bucket index, offset)
+        for bi, (bucket, gflat) in enumerate(zip(reducer.buckets, reducer.flat)):
             pflat = torch.empty_like(gflat)
             off = 0
             for p in bucket:                       # re-home every parameter inside the flat bucket (same offsets as its gradient)
                 n = p.numel()
                 pflat[off:off + n].copy_(p.data.reshape(-1))
                 p.data = pflat[off:off + n].view_as(p)
+                self._slot[p] = (bi, off)
                 off += n
             self.pflat.append(pflat)
             self.m.append(torch.zeros_like(gflat))
             self.v.append(torch.zeros_like(gflat))
         self.normsq = torch.zeros(1, dtype=torch.float32, device=reducer.flat[0].device)
+        # torch.optim order: the trainable parameters in registration order (the reducer holds them reversed, in buckets)
+        self.params = [p for p in reducer.module.parameters() if p.requires_grad]
+
+    @property
+    def param_groups(self):
+        """Read-only view in torch.optim's shape (the reference reads ``param_groups[..]['lr']``, train.py:451-455)."""
+        return [{'lr': self.lr, 'betas': self.betas, 'eps': self.eps, 'weight_decay': self.weight_decay, 'amsgrad': False,
+                 'params': list(range(len(self.params)))}]
 
     def step(self, lr=None):
         """Call after ``reducer.finish()``.  Returns the global gradient norm (device scalar, no host sync)."""
@@ -54,16 +67,47 @@ class FusedAdam:
         for p, g, m, v in zip(self.pflat, self.reducer.flat, self.m, self.v):
             lib().dx_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(self.lr), self.betas[0], self.betas[1], float(self.eps),
                                float(self.weight_decay), self.step_count, _p(self.normsq), float(self.max_norm), _stream())
-        ops.invalidate_packs()                      # parameters were written behind autograd's back: force a re-pack ...
-        ops.repack_all()                            # ... which is one launch for the whole model
+        self.runtime.invalidate_packs()             # parameters were written behind autograd's back: force a re-pack ...
+        ops.repack_all(self.runtime)                # ... which is one launch for the whole model
         return self.normsq.sqrt()
 
+    # -- checkpoint layout of torch.optim.Adam -------------------------------------------------------------------------
     def state_dict(self):
-        return {'step': self.step_count, 'lr': self.lr, 'm': [t.clone() for t in self.m], 'v': [t.clone() for t in self.v]}
+        state = {}
+        if self.step_count > 0:
+            for i, p in enumerate(self.params):
+                bi, off = self._slot[p]
+                n = p.numel()
+                state[i] = {'step': torch.tensor(float(self.step_count)),
+                            'exp_avg': self.m[bi][off:off + n].view_as(p).clone(),
+                            'exp_avg_sq': self.v[bi][off:off + n].view_as(p).clone()}
+        group = {'lr': self.lr, 'betas': self.betas, 'eps': self.eps, 'weight_decay': self.weight_decay, 'amsgrad': False,
+                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                 'decoupled_weight_decay': False, 'params': list(range(len(self.params)))}
+        return {'state': state, 'param_groups': [group]}
 
-    def load_state_dict(self, state):
-        self.step_count, self.lr = state['step'], state['lr']
-        for dst, src in zip(self.m, state['m']):
-            dst.copy_(src)
-        for dst, src in zip(self.v, state['v']):
-            dst.copy_(src)
+    def load_state_dict(self, sd):
+        groups = sd['param_groups']
+        if len(groups) != 1 or len(groups[0]['params']) != len(self.params):
+            raise ValueError(f'optimizer state has {sum(len(g["params"]) for g in groups)} parameters in {len(groups)} groups; '
+                             f'this model has {len(self.params)} in one group')
+        g = groups[0]
+        self.lr = g.get('lr', self.lr)
+        self.betas, self.eps, self.weight_decay = tuple(g.get('betas', self.betas)), g.get('eps', self.eps), g.get('weight_decay', self.weight_decay)
+        steps = set()
+        for m, v in zip(self.m, self.v):
+            m.zero_()
+            v.zero_()
+        for idx, i in enumerate(g['params']):
+            st = sd['state'].get(i)
+            if st is None:
+                continue
+            p = self.params[idx]
+            bi, off = self._slot[p]
+            n = p.numel()
+            self.m[bi][off:off + n].copy_(st['exp_avg'].reshape(-1))
+            self.v[bi][off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
+            steps.add(int(st['step']))                       # torch >= 1.12 stores a tensor, 1.9 (the reference pin) an int
+        if len(steps) > 1:
+            raise ValueError(f'per-parameter step counts differ ({sorted(steps)}): the fused kernel keeps ONE bias-correction step')
+        self.step_count = steps.pop() if steps else 0
