@@ -174,13 +174,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host_s = 0.0                                  # time the host spends ENQUEUEING a step (no sync inside): must stay below ms_per_step
     for it in range(args.steps):
         if use_events and it == args.steps - 1:
             # HIP-event bracketing of every conv-GEMM launch costs ~8 % of a step, so only the LAST timed step carries it
             lib().dx_prof_enable(0, 512)
             model.runtime.record_launches(True)
             crit.runtime.record_launches(True)
+        th = time.perf_counter()
         last = step(args.warmup + it, it)
+        host_s += time.perf_counter() - th
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -239,6 +242,7 @@ def main():
         }
         result['rccl_ranks'] = dist.get_world_size() if world > 1 else 1
         result['exposed_allreduce_ms_per_step'] = round(exposed_ms, 4)
+        result['host_enqueue_ms_per_step'] = round(1e3 * host_s / args.steps, 3)
         if roofline is not None:
             result['roofline'] = roofline
         if world == 1 and not args.no_cpu_baseline:

@@ -53,12 +53,13 @@ int dx_conv_gemm(const void* X, int ldx, const void* Wp, const float* bias, void
                  int x_bf16, int y_bf16, int aux_bf16, void* stream);
 /* x_bf16 / y_bf16 / aux_bf16 = 1: that tensor is stored as bf16 (bf16 operand mode only; ld* count elements).  Used for the
  * 1024-wide hidden activations of the conv feed-forward and the prenet, whose HBM traffic otherwise bounds the step. */
-/* G[taps][Cout][Cin] (fp32, caller-zeroed) += dY^T * shifted X   (autograd of the conv w.r.t. its weight) */
+/* G (fp32, caller-initialised, the parameter's OWN checkpoint layout (Cout, Cin, taps)) += dY^T * shifted X   (autograd of the conv
+ * w.r.t. its weight, train.py:435 loss.backward()).  G may be a zeroed scratch gradient or a live `.grad` / all-reduce bucket view. */
 int dx_conv_wgrad(const void* dY, int ldy, const void* X, int ldx, float* G,
                   int B, int N, int Cin, int Cout, int taps, const int* lens, int skip_halo,
                   int bf16, int dy_bf16, int x_bf16, float* dbias, void* stream);
 /* dbias (optional, caller-zeroed [Cout]): the bias gradient sum_rows dY is accumulated by the same launch from the staged dY tiles */
-/* grad (Cout, Cin, taps) (+)= G[taps][Cout][Cin] */
+/* grad (Cout, Cin, taps) (+)= G[taps][Cout][Cin]   (re-layout helper; dx_conv_wgrad itself now writes the parameter layout) */
 int dx_unpack_wgrad(const float* G, float* grad, int Cout, int Cin, int taps, int accumulate, void* stream);
 /* out[c] += sum_rows X[row][c]   (bias gradients) */
 int dx_colsum(const void* X, int ldx, float* out, long rows, int C, int x_bf16, void* stream);

@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int co = co0 + wc * 64 + i * 16 + g * 4 + e;
-        if (co < a.Cout) atomicAdd(&a.G[((size_t)tap * a.Cout + co) * a.Cin + ci], acc[i][j][e]);
+        if (co < a.Cout) atomicAdd(&a.G[((size_t)co * a.Cin + ci) * TAPS + tap], acc[i][j][e]);   // the parameter's own (Cout, Cin, taps) layout
       }
     }
   if (do_bias && co0 + tid < a.Cout && bsum != 0.f) atomicAdd(&a.dbias[co0 + tid], bsum);
@@ -1137,8 +1137,12 @@ __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel
   constexpr int XU = XH ? CI_T / 8 : CI_T / 4, XE = XH ? 8 : 4;   // per X row (CI_T channels)
   constexpr int D_IT = WB_BK * DU / NT;
   constexpr int X_IT = (XROWS * XU + NT - 1) / NT;
-  __shared__ __attribute__((aligned(16))) __bf16 Ds[WB_BK * WB_LD];
-  __shared__ __attribute__((aligned(16))) __bf16 Xs[(WB_BK + 8) * WB_LD];   // rows beyond the halo stay zero so every tr read is in bounds
+  // ONE LDS array: the dY tile, the X tile (rows beyond the halo stay zero so every tr read is in bounds), and - after the chunk
+  // loop - the fp32 staging tile of the epilogue
+  constexpr int SMEM_BYTES = (2 * WB_BK + 8) * WB_LD * 2;
+  __shared__ __attribute__((aligned(16))) __bf16 smem_all[(2 * WB_BK + 8) * WB_LD];
+  __bf16* const Ds = smem_all;
+  __bf16* const Xs = smem_all + WB_BK * WB_LD;
   const int ci_tiles = (a.Cin + CI_T - 1) / CI_T;
   const int co0 = (blockIdx.x / ci_tiles) * TILE;
   const int ci0 = (blockIdx.x % ci_tiles) * CI_T;
@@ -1270,8 +1274,12 @@ __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel
   }
 #undef DX_WG_LOAD
 #undef DX_WG_STORE
-#pragma unroll
-  for (int t = 0; t < TAPS; ++t)
+  // Epilogue: the partial sums go into the gradient in the PARAMETER's own layout (Cout, Cin, taps) - no re-layout launch, no
+  // scratch tensor.  A lane holds 4 output channels x 1 input channel per accumulator, i.e. its addresses in that layout are
+  // 4 rows x 12-byte strides; instead the tile is transposed through LDS, 32 (or 16) output-channel rows at a time, and every
+  // wave-instruction adds 64 CONSECUTIVE floats of one row (256 contiguous bytes: the full-rate shape of the memory-side float
+  // atomics, MI355X_MICROARCH.md "Global float atomics").
+  if constexpr (TAPS == 1) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1281,11 +1289,40 @@ __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int co = co0 + wc * 64 + i * 16 + g * 4 + e;
-          if (co < a.Cout && acc[t][i][j][e] != 0.f) atomicAdd(&a.G[((size_t)t * a.Cout + co) * a.Cin + ci], acc[t][i][j][e]);
+          if (co < a.Cout && acc[0][i][j][e] != 0.f) atomicAdd(&a.G[(size_t)co * a.Cin + ci], acc[0][i][j][e]);
         }
       }
+  } else {
+    constexpr int ROWF = CI_T * TAPS;                              // floats per staged row: [ci][tap]
+    constexpr int RPP = (SMEM_BYTES >= 32 * ROWF * 4) ? 32 : 16;   // rows per pass
+    float* const stage = reinterpret_cast<float*>(smem_all);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int half = 0; half < 32 / RPP; ++half) {
+        __syncthreads();                                           // chunk loop / previous pass: every LDS read has retired
+        if (RPP == 32 || wc == half) {
+          const int rowbase = RPP == 32 ? wc * 16 : 0;
+#pragma unroll
+          for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                stage[(rowbase + g * 4 + e) * ROWF + (wt * 32 + j * 16 + r) * TAPS + t] = acc[t][i][j][e];
+        }
+        __syncthreads();
+        for (int u = tid; u < RPP * ROWF; u += NT) {               // ROWF % 64 == 0: a wave-instruction stays inside one row
+          const int row = u / ROWF, c = u - row * ROWF;
+          const int co = co0 + (RPP == 32 ? (row >> 4) * 64 + i * 16 + (row & 15) : half * 64 + i * 16 + row);
+          const float v = stage[u];
+          if (co < a.Cout && ci0 + c / TAPS < a.Cin && v != 0.f) atomicAdd(&a.G[((size_t)co * a.Cin + ci0) * TAPS + c], v);
+        }
+      }
+    }
+  }
   if (do_bias) {                                         // workgroup-uniform: fold the row slices, one atomic per channel
-    float* red = reinterpret_cast<float*>(Ds);           // the chunk loop is over: its last barrier has retired every tile read
+    float* red = reinterpret_cast<float*>(Ds);           // the chunk loop and the staging passes are over
     __syncthreads();
     red[(tid >> 6) * TILE + (tid & 63) * 2] = bsum0;
     red[(tid >> 6) * TILE + (tid & 63) * 2 + 1] = bsum1;
@@ -1552,7 +1589,8 @@ int dx_conv_gemm(const void* Xv, int ldx, const void* Wp, const float* bias, voi
   return DX_OK;
 }
 
-// G[taps][Cout][Cin] (fp32, caller-zeroed) += dY^T * shift(X); then dx_unpack_wgrad moves it to (Cout, Cin, taps).
+// G (fp32, caller-initialised, the PARAMETER's own layout (Cout, Cin, taps)) += dY^T * shift(X): a weight gradient, or a
+// pre-zeroed / running `.grad` view to accumulate into.
 int dx_conv_wgrad(const void* dY, int ldy, const void* X, int ldx, float* G,
                   int B, int N, int Cin, int Cout, int taps, const int* lens, int skip_halo,
                   int bf16, int dy_bf16, int x_bf16, float* dbias, void* stream) {

@@ -276,23 +276,13 @@ def conv_wgrad(dy, x, pack: PackedWeight, lens=None, halo=-1, bias=True, arena=N
     dY, accumulated by the same launch).  ``w_sink`` / ``b_sink``: pre-zeroed ``.grad`` tensors to accumulate into directly
     (the corresponding return value is then None)."""
     B_, N_ = (1, x.shape[0]) if x.dim() == 2 else (x.shape[0], x.shape[1])
-    direct = w_sink is not None and pack.taps == 1          # Linear: G has the parameter's own layout
-    g = w_sink.view(-1) if direct else _zeros(arena, pack.taps * pack.cout * pack.cin, device=x.device)
+    # the kernel accumulates in the parameter's own (Cout, Cin, taps) layout: straight into the sink, or into a fresh gradient
+    g = w_sink if w_sink is not None else _zeros(arena, *pack.weight.shape, device=x.device)
     db = b_sink if b_sink is not None else (_zeros(arena, pack.cout, device=x.device) if bias else None)
     _log(pack, ('wgrad', B_ * N_, N_, pack.cin, pack.cout, pack.taps))
     lib().dx_conv_wgrad(_p(dy), _rows(dy), _p(x), _rows(x), _p(g), B_, N_, pack.cin, pack.cout, pack.taps, _p(lens), int(halo),
                         _half(prec or pack.rt.precision), _is_bf16(dy), _is_bf16(x), _p(db), _stream())
-    db_ret = None if b_sink is not None else db
-    if direct:
-        return None, db_ret
-    if pack.taps == 1:
-        return g.view(pack.weight.shape), db_ret
-    if w_sink is not None:
-        lib().dx_unpack_wgrad(_p(g), _p(w_sink), pack.cout, pack.cin, pack.taps, 1, _stream())
-        return None, db_ret
-    grad = torch.empty(pack.weight.shape, dtype=torch.float32, device=x.device)
-    lib().dx_unpack_wgrad(_p(g), _p(grad), pack.cout, pack.cin, pack.taps, 0, _stream())
-    return grad, db_ret
+    return (None if w_sink is not None else g), (None if b_sink is not None else db)
 
 
 def colsum(x, C=None):
