@@ -61,6 +61,15 @@ int dx_conv_wgrad(const void* dY, int ldy, const void* X, int ldx, float* G,
 /* dbias (optional, caller-zeroed [Cout]): the bias gradient sum_rows dY is accumulated by the same launch from the staged dY tiles */
 /* grad (Cout, Cin, taps) (+)= G[taps][Cout][Cin]   (re-layout helper; dx_conv_wgrad itself now writes the parameter layout) */
 int dx_unpack_wgrad(const float* G, float* grad, int Cout, int Cin, int taps, int accumulate, void* stream);
+/* Fused conv feed-forward pair (model.py:206-217 PositionWiseConvFF.forward: conv k3 128->F, ReLU, conv k3 F->128) and the
+ * input-gradient chain of the same pair, bf16 MFMA operands, ONE launch; the F-wide hidden tensor is consumed from LDS.
+ *   Y[b,n,:] (+)= bias_b + conv3(Wb, Hm)[b,n,:],   Hm = mid(bias_a + conv3(Wa, X)),  H <- Hm (bf16, kept for the weight gradients)
+ * X [B][N][128] bf16; Wa / Wb: bf16 packs of dx_pack_weights (forward: conv1.fwd, conv2.fwd; backward: conv2.bwd, conv1.bwd);
+ * mid = ReLU if relu_mid; aux (bf16 [B][N][F], optional): mid zeroes every position where aux <= 0 (ReLU backward).
+ * Token tiles starting at or beyond min(lens[b] + skip_halo, N) are padding nobody reads: zero-filled (H, and Y unless accumulate). */
+int dx_ff_pair(const void* X, int ldx, const void* Wa, const void* Wb, const float* bias_a, const float* bias_b,
+               const void* aux, int ld_aux, void* H, int ldh, float* Y, int ldy,
+               int B, int N, int F, int relu_mid, int accumulate, const int* lens, int skip_halo, void* stream);
 /* out[c] += sum_rows X[row][c]   (bias gradients) */
 int dx_colsum(const void* X, int ldx, float* out, long rows, int C, int x_bf16, void* stream);
 

@@ -544,3 +544,52 @@ def test_loss_kernels(ops):
     s = ops.pitch_mse(pp.detach(), gt, lens)
     assert abs(s[0].item() / (s[1].item() + 1e-5) - pl.item()) < 1e-5 * max(1, pl.item())
     assert rel_err(ops.pitch_grad(pp.detach(), gt, lens, s, 0.15), pp.grad) < 1e-5
+
+
+@pytest.mark.parametrize('B,N,lens', [(5, 300, [300, 253, 252, 127, 1]), (3, 126, [126, 125, 60]), (4, 127, [127, 126, 3, 64]),
+                                      (2, 1000, [1000, 881]), (3, 379, [379, 378, 377])])
+def test_ff_pair_fused_matches_two_launches_and_torch(ops, B, N, lens):
+    """csrc/dx_ffpair.hip (one launch, hidden tensor consumed from LDS, 126-token tiles) against the two-launch path it replaces
+    and against fp32 PyTorch on the same bf16-rounded operands: forward pair and input-gradient pair, lengths on both sides of
+    the 126-token tile edges."""
+    D, Fc = 128, 1024
+    ops.set_precision('bf16')
+    try:
+        w1 = randn(Fc, D, 3, seed=1, scale=1.0 / math.sqrt(3 * D))
+        b1 = randn(Fc, seed=2, scale=0.1)
+        w2 = randn(D, Fc, 3, seed=3, scale=1.0 / math.sqrt(3 * Fc))
+        b2 = randn(D, seed=4, scale=0.1)
+        p1, p2 = ops.PackedWeight(w1), ops.PackedWeight(w2)
+        L = lens_tensor(lens)
+        valid = (torch.arange(N, device=DEV)[None, :] < L[:, None]).float()[:, :, None]
+        x = (randn(B, N, D, seed=5) * valid).to(torch.bfloat16)             # like a masked LayerNorm output
+        # ---- forward ----
+        h_ref = ops.conv_gemm(x, p1, b1, relu=True, lens=L, halo=1, out_dtype=torch.bfloat16)
+        z_ref = ops.conv_gemm(h_ref, p2, b2, lens=L, halo=0)
+        z, h = ops.ff_pair(x, p1, p2, b1, b2, L)
+        xf, w1f, w2f = x.float(), w1.to(torch.bfloat16).float(), w2.to(torch.bfloat16).float()
+        h_t = torch.relu(F.conv1d(xf.transpose(1, 2), w1f, b1, padding=1)).to(torch.bfloat16).float()
+        z_t = F.conv1d(h_t, w2f, b2, padding=1).transpose(1, 2)
+        for b, n in enumerate(lens):
+            hn = min(n + 1, N)                                               # hidden rows that anything reads: 0 .. len (incl. the halo row)
+            assert (h[b, :hn].float() - h_ref[b, :hn].float()).abs().max() <= 2e-2 * h_ref[b, :hn].float().abs().max()
+            assert rel_err(z[b, :n], z_ref[b, :n]) < 2e-3
+            assert rel_err(z[b, :n], z_t[b, :n]) < 1e-2
+            assert rel_err(h[b, :hn].float(), h_t[b, :, :hn].t()) < 1e-2
+        assert torch.isfinite(h.float()).all() and torch.isfinite(z).all()   # padding tiles are defined (zero-filled)
+        # ---- input-gradient pair: dz -> (mask by h > 0) -> dx, accumulated into the residual-branch gradient ----
+        dz = (randn(B, N, D, seed=6) * valid).to(torch.bfloat16)
+        base = randn(B, N, D, seed=7)
+        dh_ref = ops.conv_gemm(dz, p2, None, transpose=True, relu_aux=h_ref, lens=L, halo=1, out_dtype=torch.bfloat16)
+        dx_ref = ops.conv_gemm(dh_ref, p1, None, transpose=True, out=base.clone(), accumulate=True, lens=L, halo=0)
+        dx, dh = ops.ff_pair(dz, p1, p2, None, None, L, backward=True, aux=h_ref, out=base.clone(), accumulate=True)
+        dh_t = F.conv_transpose1d(dz.float().transpose(1, 2), w2f, padding=1) * (h_t > 0)
+        dx_t = base + F.conv_transpose1d(dh_t.to(torch.bfloat16).float(), w1f, padding=1).transpose(1, 2)
+        for b, n in enumerate(lens):
+            hn = min(n + 1, N)
+            assert (dh[b, :hn].float() - dh_ref[b, :hn].float()).abs().max() <= 2e-2 * dh_ref[b, :hn].float().abs().max().clamp_min(1e-6)
+            assert rel_err(dx[b, :n], dx_ref[b, :n]) < 2e-3
+            assert rel_err(dx[b, :n], dx_t[b, :n]) < 1e-2
+        assert torch.isfinite(dh.float()).all() and torch.isfinite(dx).all()
+    finally:
+        ops.set_precision('f32')

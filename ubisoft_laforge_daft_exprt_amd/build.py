@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(PKG, 'libdaft_exprt_hip.so')
-SOURCES = ['dx_runtime.hip', 'dx_gemm.hip', 'dx_attention.hip', 'dx_rows.hip', 'dx_upsample.hip', 'dx_loss.hip', 'dx_optim.hip']
+SOURCES = ['dx_runtime.hip', 'dx_gemm.hip', 'dx_ffpair.hip', 'dx_attention.hip', 'dx_rows.hip', 'dx_upsample.hip', 'dx_loss.hip', 'dx_optim.hip']
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wno-unused-value', '-Wno-unused-result']
 
 

@@ -244,6 +244,29 @@ def conv_gemm(x, pack: PackedWeight, bias=None, *, transpose=False, relu=False, 
     return out
 
 
+def ff_pair(x, pack1: PackedWeight, pack2: PackedWeight, bias1, bias2, lens, *, backward=False, aux=None, out=None, accumulate=False,
+            halo=1):
+    """The conv feed-forward pair in ONE launch (bf16 operand mode; csrc/dx_ffpair.hip).
+    forward : (z, h)  with h = relu(conv1(x) + b1) [bf16, kept for the weight gradients], z = conv2(h) + b2 [fp32]
+    backward: (dx, dh) with x = d(loss)/dz as bf16, dh = conv2^T(x) masked by ``aux`` = h > 0 [bf16], dx (+)= conv1^T(dh)
+    ``pack1`` / ``pack2`` are the packs of conv1 (F, 128, 3) and conv2 (128, F, 3) in both directions."""
+    if x.dtype != torch.bfloat16:
+        raise TypeError('ff_pair runs in bf16 operand mode on a bf16 activation tensor')
+    B, N, D = x.shape
+    Fc = pack1.cout
+    if D != 128 or pack1.cin != 128 or pack2.cout != 128 or pack2.cin != Fc or pack1.taps != 3 or pack2.taps != 3:
+        raise ValueError('ff_pair is built for conv(k=3, 128 -> F) -> conv(k=3, F -> 128)')
+    i1, i2 = pack1.image('bf16'), pack2.image('bf16')
+    wa, wb = (i2.bwd, i1.bwd) if backward else (i1.fwd, i2.fwd)
+    h = torch.empty(B, N, Fc, dtype=torch.bfloat16, device=x.device)
+    if out is None:
+        out = torch.empty(B, N, 128, dtype=torch.float32, device=x.device)
+    _log(pack1, ('ffpair', B * N, N, 128, Fc, 3))
+    lib().dx_ff_pair(_p(x), _rows(x), _p(wa), _p(wb), _p(bias1), _p(bias2), _p(aux), 0 if aux is None else _rows(aux), _p(h), _rows(h),
+                     _p(out), _rows(out), B, N, Fc, int(not backward), int(accumulate), _p(lens), int(halo), _stream())
+    return out, h
+
+
 class ZeroArena:
     """One zero-filled buffer handed out in 16-byte aligned slices: the many small accumulators (atomic targets) of one
     backward call cost a single memset launch instead of one each."""
