@@ -1,0 +1,69 @@
+"""Where a workgroup of the fused feed-forward kernel spends its cycles: builds csrc/dx_ffpair.hip with -DDX_FFPAIR_STAMPS (s_memtime
+stamps per phase, written to a buffer nothing else reads) into a scratch library and prints per-phase medians over the live workgroups.
+Diagnostic only: the product library carries no stamps."""
+import ctypes, math, os, subprocess, sys, tempfile
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch
+from ubisoft_laforge_daft_exprt_amd import ops
+from ubisoft_laforge_daft_exprt_amd.synth import CONFIGS, synthetic_batch
+
+
+def main():
+    csrc = os.path.join(REPO, 'ubisoft_laforge_daft_exprt_amd', 'csrc')
+    so = os.path.join(tempfile.mkdtemp(), 'libffp_diag.so')
+    subprocess.run(['hipcc', '-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-shared', '-DDX_FFPAIR_STAMPS', '-w', '-DDX_FP_ABL=' + os.environ.get('DX_FP_ABL', '0'),
+                    os.path.join(csrc, 'dx_ffpair.hip'), os.path.join(csrc, 'dx_runtime.hip'), '-o', so], check=True)
+    dll = ctypes.CDLL(so)
+    dev = 'cuda'
+    backward = len(sys.argv) > 1 and sys.argv[1] == 'bwd'
+    ops.set_precision('bf16')
+    batch = synthetic_batch(**CONFIGS['C2'])
+    lens = batch[9].to(dev).to(torch.int32)
+    if len(sys.argv) > 2:                                   # e.g. "fwd 8": only the first 8 utterances (few workgroups: an idle chip)
+        lens = lens[:int(sys.argv[2])].contiguous()
+    B, N, D, Fc = lens.numel(), int(lens.max()), 128, 1024
+    g = torch.Generator().manual_seed(0)
+    rn = lambda *s, sc=1.0: (sc * torch.randn(*s, generator=g)).to(dev)
+    w1, b1, w2, b2 = rn(Fc, D, 3, sc=1 / math.sqrt(3 * D)), rn(Fc, sc=0.1), rn(D, Fc, 3, sc=1 / math.sqrt(3 * Fc)), rn(D, sc=0.1)
+    p1, p2 = ops.PackedWeight(w1), ops.PackedWeight(w2)
+    i1, i2 = p1.image('bf16'), p2.image('bf16')
+    valid = (torch.arange(N, device=dev)[None, :] < lens[:, None]).float()[:, :, None]
+    x = (rn(B, N, D) * valid).to(torch.bfloat16)
+    h = torch.empty(B, N, Fc, dtype=torch.bfloat16, device=dev)
+    aux = ops.conv_gemm(x, p1, b1, relu=True, lens=lens, halo=1, out_dtype=torch.bfloat16) if backward else None
+    y = torch.zeros(B, N, D, device=dev)
+    nwg = B * ((N + 125) // 126)
+    stamps = torch.zeros(nwg, 2, 16, dtype=torch.int64, device=dev)
+    dll.dx_ff_pair_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
+    P = lambda t: ctypes.c_void_p(None if t is None else t.data_ptr())
+    wa, wb = (i2.bwd, i1.bwd) if backward else (i1.fwd, i2.fwd)
+    for _ in range(3):
+        rc = dll.dx_ff_pair(P(x), 128, P(wa), P(wb), P(None if backward else b1), P(None if backward else b2), P(aux), Fc, P(h), Fc, P(y), 128,
+                            B, N, Fc, int(not backward), int(backward), P(lens), 1, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+    torch.cuda.synchronize()
+    st = stamps.cpu()
+    live = st[:, 0, 15] > 0
+    st = st[live & (st[:, 0, 3] > 0)]                        # workgroups that ran the slice loop
+    print(f'{"bwd" if backward else "fwd"}: {st.shape[0]} live workgroups of {nwg}')
+    names = ['tile search', 'stage x + first weight loads'] + [f'iteration {i}' for i in range(9)] + ['final epilogue']
+    idx = [0, 1, 2] + [3 + i for i in range(9)] + [15]
+    for role, rname in ((0, 'producer'), (1, 'consumer')):
+        d = st[:, role, idx][:, 1:] - st[:, role, idx][:, :-1]
+        med = d.float().median(dim=0).values
+        tot = (st[:, role, 15] - st[:, role, 0]).float()
+        print(f'  {rname}: total median {tot.median():.0f} cycles (min {tot.min():.0f}, max {tot.max():.0f})')
+        for n_, m in zip(names, med):
+            print(f'      {n_:32s} {m:8.0f}')
+    for role, rname, marks in ((0, 'producer', ('copy-out', 'matrix steps', 'epilogue', 'barrier wait')), (1, 'consumer', ('copy-out', 'matrix steps', 'barrier wait'))):
+        t = st[:, role]
+        pts = [t[:, 6], t[:, 12], t[:, 13]] + ([t[:, 14]] if role == 0 else []) + [t[:, 7]]
+        d = [(b_ - a_).float().median().item() for a_, b_ in zip(pts[:-1], pts[1:])]
+        print(f'  {rname}, iteration 4: ' + ', '.join(f'{m} {v:.0f}' for m, v in zip(marks, d)))
+    span = (st[:, :, 15].max() - st[:, :, 0].min()).item()
+    print(f'  first start -> last end: {span} cycles')
+
+
+if __name__ == '__main__':
+    main()

@@ -158,13 +158,17 @@ class FFTBlockFn(torch.autograd.Function):
         ln1 = ops.ln_fwd(z1, x, ln1_w, ln1_b, None, lens.i32, seed_pre=s_ln1, p_pre=p_attn, shadow=sh)
         y1, mean1, rstd1 = ln1[:3]
         y1g = ln1[3] if sh else y1                 # the copy the GEMMs read
-        h = ops.conv_gemm(y1g, packs['c1'], c1_b, relu=True, lens=L, halo=1, out_dtype=hd, prec=prec)   # conv2 reads one row past the end
-        z2 = ops.conv_gemm(h, packs['c2'], c2_b, lens=L, halo=0, prec=prec)
+        fused = ops.ff_pair_applies(y1g, packs['c1'], packs['c2'], prec)
+        if fused:      # conv1 + ReLU + conv2 in ONE launch, the 1024-wide hidden tile consumed from LDS (h is still written: weight gradients)
+            z2, h = ops.ff_pair(y1g, packs['c1'], packs['c2'], c1_b, c2_b, L)
+        else:
+            h = ops.conv_gemm(y1g, packs['c1'], c1_b, relu=True, lens=L, halo=1, out_dtype=hd, prec=prec)   # conv2 reads one row past the end
+            z2 = ops.conv_gemm(h, packs['c2'], c2_b, lens=L, halo=0, prec=prec)
         y2, mean2, rstd2 = ops.ln_fwd(z2, y1, ln2_w, ln2_b, film, lens.i32, seed_pre=s_ln2, p_pre=p_conv)
         ctx.save_for_backward(x, film, qkv, att, lse, z1, mean1, rstd1, y1g, h, z2, mean2, rstd2, ln1_w, ln1_b, ln2_w, ln2_b)
         ctx.lens, ctx.packs, ctx.heads = lens, packs, heads
         ctx.drop = (p_attn, p_conv, s_attn, s_ln1, s_ln2)
-        ctx.prec, ctx.sink = prec, rt.sink
+        ctx.prec, ctx.sink, ctx.fused = prec, rt.sink, fused
         return y2
 
     @staticmethod
@@ -188,9 +192,12 @@ class FFTBlockFn(torch.autograd.Function):
         dz2, da2, dln2_w, dln2_b, dfilm = r2[:5]
         dff = r2[5] if sh else (da2 if da2 is not None else dz2)      # gradient w.r.t. the conv2 output, as the GEMMs read it
         dc2_w, dc2_b = ops.conv_wgrad(dff, h, packs['c2'], L, 0, arena=arena, w_sink=g('c2_w'), b_sink=g('c2_b'), prec=prec)
-        dh = ops.conv_gemm(dff, packs['c2'], None, transpose=True, relu_aux=h, lens=L, halo=1, out_dtype=h.dtype, prec=prec)
+        if ctx.fused:  # conv2^T -> ReLU mask -> conv1^T in one launch, accumulated into the residual-branch gradient
+            dy1, dh = ops.ff_pair(dff, packs['c1'], packs['c2'], None, None, L, backward=True, aux=h, out=dz2, accumulate=True)
+        else:
+            dh = ops.conv_gemm(dff, packs['c2'], None, transpose=True, relu_aux=h, lens=L, halo=1, out_dtype=h.dtype, prec=prec)
+            dy1 = ops.conv_gemm(dh, packs['c1'], None, transpose=True, out=dz2, accumulate=True, lens=L, halo=0, prec=prec)  # + residual branch
         dc1_w, dc1_b = ops.conv_wgrad(dh, y1, packs['c1'], L, 1, arena=arena, w_sink=g('c1_w'), b_sink=g('c1_b'), prec=prec)
-        dy1 = ops.conv_gemm(dh, packs['c1'], None, transpose=True, out=dz2, accumulate=True, lens=L, halo=0, prec=prec)  # + residual branch
         r1 = ops.ln_bwd(dy1, z1, mean1, rstd1, ln1_w, ln1_b, None, L, want_da=p_attn > 0, seed_pre=s_ln1,
                         p_pre=p_attn, arena=arena, w_sink=g('ln1_w'), b_sink=g('ln1_b'), shadow=sh)
         dz1, da1, dln1_w, dln1_b = r1[:4]
