@@ -23,20 +23,6 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0}   # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md §Chip-level parameters
-
-
-def conv_algorithmic_flops(log, valid_by_axis):
-    """Algorithmic FLOPs (valid tokens only, multiply-add = 2: SURVEY.md §8d) of the recorded conv-GEMM launches."""
-    total = 0.0
-    for kind, rows, n, cin, cout, taps in log:
-        if kind != 'conv':
-            continue
-        valid = valid_by_axis.get(n, rows) if rows != n else rows
-        total += 2.0 * taps * cin * cout * valid
-    return total
-
-
 def cpu_baseline(hp, n_threads, config, n_speakers):
     """The CPU oracle (a port that keeps the reference's op structure, so its cost is the reference's cost: BASELINE.md) on the
     SAME synthetic batch as the GPU number: 1 warm-up + up to 3 timed steps of forward + loss (pitch predictor included) +
@@ -101,6 +87,7 @@ def main():
     ap.add_argument('--config', default='C2', choices=['C1', 'C2', 'C5'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--kernel-table', default='', help='write the per-kernel roofline table of the last timed step to this JSON file')
     ap.add_argument('--no-dropout', action='store_true', help='diagnostic only: the headline metric is measured with dropout on')
     args = ap.parse_args()
 
@@ -121,7 +108,7 @@ def main():
 
     import ubisoft_laforge_daft_exprt_amd as pkg
     from ubisoft_laforge_daft_exprt_amd import ops
-    from ubisoft_laforge_daft_exprt_amd._lib import lib
+    from ubisoft_laforge_daft_exprt_amd import _lib
     from ubisoft_laforge_daft_exprt_amd.ddp import GradientReducer
     from ubisoft_laforge_daft_exprt_amd.synth import CONFIGS, synthetic_batch, synthetic_state_dict
 
@@ -174,16 +161,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    records = []
     host_s = 0.0                                  # time the host spends ENQUEUEING a step (no sync inside): must stay below ms_per_step
     for it in range(args.steps):
         if use_events and it == args.steps - 1:
-            # HIP-event bracketing of every conv-GEMM launch costs ~8 % of a step, so only the LAST timed step carries it
-            lib().dx_prof_enable(0, 512)
-            model.runtime.record_launches(True)
-            crit.runtime.record_launches(True)
+            # event bracketing of every launch costs ~10 % of a step, so only the LAST timed step carries it
+            _lib.set_timer(records)
         th = time.perf_counter()
         last = step(args.warmup + it, it)
         host_s += time.perf_counter() - th
+    _lib.set_timer(None)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -203,26 +190,33 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         exposed_ms = float(te[0])
 
-    roofline = None
-    if use_events:
-        import ctypes
-        n, ms = ctypes.c_int(0), ctypes.c_double(0.0)
-        lib().dx_prof_collect(0, ctypes.cast(ctypes.pointer(n), ctypes.c_void_p), ctypes.cast(ctypes.pointer(ms), ctypes.c_void_p))
-        log = (model.runtime.record_launches(False) or []) + (crit.runtime.record_launches(False) or [])
-        flops = conv_algorithmic_flops(log, {int(batch[9].max()): frames, int(batch[5].max()): symbols})
-        if n.value > 0 and ms.value > 0:
-            achieved = flops / (ms.value * 1e-3) / 1e12
+    roofline = roofline_hbm = table = None
+    if use_events and rank == 0:
+        from ubisoft_laforge_daft_exprt_amd import profiling
+        geom = profiling.Geometry([batch[9].tolist(), batch[5].tolist()])
+        table = profiling.summarize(records, geom, args.precision)
+        step_us = 1e6 * elapsed / args.steps
+        mfma = [(k, v) for k, v in table.items() if v['bound'] == 'mfma']
+        if mfma:
+            k, v = mfma[0]                                            # the single kernel with the most time in the step
             traffic = None
-            pmc = os.path.join(REPO, 'profiles', 'r01_conv_gemm_pmc.json')
+            pmc = os.path.join(REPO, 'profiles', 'r02_pmc_traffic.json')
             if os.path.exists(pmc):
                 with open(pmc) as f:
-                    traffic = json.load(f).get(args.precision, {}).get('hbm_bytes_per_launch')
-            roofline = {'bound': 'mfma', 'kernel': 'conv-GEMM family: conv_ws_kernel / conv_dk_kernel / conv_gemm_kernel (Conv1d/Linear as MFMA GEMM, forward + input gradient)',
-                        'achieved': round(achieved, 2), 'peak': PEAK_TFLOPS[args.precision], 'unit': 'TFLOP/s',
-                        'frac': round(achieved / PEAK_TFLOPS[args.precision], 4), 'traffic': traffic,
-                        'launches': n.value, 'avg_launch_us': round(1e3 * ms.value / n.value, 2),
-                        'share_of_step': round(ms.value * 1e-3 / (elapsed / args.steps), 3),
-                        'measured_on': 'every conv-GEMM launch of the last timed step'}
+                    traffic = json.load(f).get(args.precision, {}).get(k, {}).get('hbm_bytes_per_launch')
+            roofline = {'bound': 'mfma', 'kernel': k, 'achieved': v['achieved'], 'peak': v['peak'], 'unit': 'TFLOP/s', 'frac': v['frac'],
+                        'traffic': traffic, 'algorithmic_bytes_per_launch': v['algorithmic_bytes_per_launch'], 'launches': v['launches'],
+                        'avg_launch_us': v['avg_us'], 'share_of_step': round(v['total_us'] / step_us, 3),
+                        'measured_on': 'events around every launch of this kernel in the last timed step',
+                        'other_mfma_kernels': {kk: {'frac': vv['frac'], 'achieved': vv['achieved'], 'launches': vv['launches'], 'avg_us': vv['avg_us'],
+                                                    'share_of_step': round(vv['total_us'] / step_us, 3)} for kk, vv in mfma[1:8]}}
+        roofline_hbm = {k: {'achieved': v['achieved'], 'unit': 'GB/s', 'peak': v['peak'], 'frac': v['frac'], 'launches': v['launches'],
+                            'avg_us': v['avg_us'], 'algorithmic_bytes_per_launch': v['algorithmic_bytes_per_launch'],
+                            'share_of_step': round(v['total_us'] / step_us, 3)}
+                        for k, v in table.items() if v['bound'] == 'hbm' and 'achieved' in v and v['total_us'] / step_us >= 0.002}
+        if args.kernel_table:
+            with open(args.kernel_table, 'w') as f:
+                json.dump({'precision': args.precision, 'config': args.config, 'ms_per_step': 1e3 * elapsed / args.steps, 'kernels': table}, f, indent=1)
 
     if rank == 0:
         result = {
@@ -245,6 +239,8 @@ def main():
         result['host_enqueue_ms_per_step'] = round(1e3 * host_s / args.steps, 3)
         if roofline is not None:
             result['roofline'] = roofline
+        if roofline_hbm:
+            result['roofline_hbm'] = roofline_hbm
         if world == 1 and not args.no_cpu_baseline:
             avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
             cores = min(avail, 16)                                       # a 1-GPU box is given a 16-CPU share

@@ -125,3 +125,22 @@ def test_feature_reader_and_collate_vs_reference_golden(tmp_path):
         f.write('1.0\n')                                     # corrupt: one frame too many
     with pytest.raises(ValueError, match='frames_pitch'):
         read_utterance(*rows[0], hp)
+
+
+def test_every_launching_entry_point_can_be_priced():
+    """profiling.price() (bench.py's per-kernel roofline accounting) accepts the argument list of every C-ABI launch function."""
+    from ubisoft_laforge_daft_exprt_amd import profiling
+    from ubisoft_laforge_daft_exprt_amd._lib import parse_header
+    geom = profiling.Geometry([[5, 9, 12], [3, 4]])
+    for name, (_, _, argnames) in parse_header(with_names=True).items():
+        if 'stream' not in argnames:
+            continue
+        args = {k: 8 for k in argnames}
+        args.update(B=3, N=12, bf16=1)
+        label, bound, flops, byt = profiling.price(name, args, geom)
+        assert isinstance(label, str) and bound in ('mfma', 'hbm')
+        assert flops is None or flops > 0
+        assert byt is None or byt >= 0
+    # valid rows, not padded rows, are credited
+    a = dict(B=3, N=12, Cin=128, Cout=128, taps=3, bf16=1, x_bf16=0, y_bf16=0, aux_bf16=0, accumulate=0, relu_aux=0, lens=1)
+    assert profiling.price('dx_conv_gemm', a, geom)[2] == 2.0 * 3 * 128 * 128 * (5 + 9 + 12)

@@ -16,28 +16,42 @@ _SCALARS = {'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float,
             'uint64_t': ctypes.c_uint64, 'uint32_t': ctypes.c_uint32}
 
 
-def parse_header(path: str = HEADER):
-    """-> {name: (restype, [argtypes])} for every function declared in the header."""
+def parse_header(path: str = HEADER, with_names: bool = False):
+    """-> {name: (restype, [argtypes])} for every function declared in the header (``with_names``: + [argument names])."""
     text = open(path).read()
     text = re.sub(r'/\*.*?\*/', ' ', text, flags=re.S)
     protos = {}
     for ret, name, args in re.findall(r'\b(int|const char\*)\s+(dx_\w+)\s*\(([^)]*)\)\s*;', text):
-        argtypes = []
+        argtypes, argnames = [], []
         args = args.strip()
         if args and args != 'void':
             for a in args.split(','):
                 a = a.strip()
+                argnames.append(re.split(r'[\s*]+', a)[-1])
                 if '*' in a:
                     argtypes.append(ctypes.c_void_p)
                 else:
                     base = a.replace('const ', '').split()[0]
                     argtypes.append(_SCALARS[base])
-        protos[name] = (ctypes.c_int if ret == 'int' else ctypes.c_char_p, argtypes)
+        restype = ctypes.c_int if ret == 'int' else ctypes.c_char_p
+        protos[name] = (restype, argtypes, argnames) if with_names else (restype, argtypes)
     return protos
 
 
 class DxError(RuntimeError):
     pass
+
+
+# Diagnostic hook (bench.py / tools only; never read by any computation): when set to a list, every C-ABI launch is bracketed by
+# two events on torch's current stream -- the stream the kernels are launched on -- and appended as
+# (entry point, {argument name: value}, start event, stop event).  profiling.py prices the records.
+TIMER = None
+
+
+def set_timer(records):
+    global TIMER
+    old, TIMER = TIMER, records
+    return old
 
 
 class _Lib:
@@ -48,7 +62,7 @@ class _Lib:
                 '(hipcc --offload-arch=gfx950). There is no fallback path.')
         self._dll = ctypes.CDLL(LIB_PATH)
         self._last_error = None
-        for name, (restype, argtypes) in parse_header().items():
+        for name, (restype, argtypes, argnames) in parse_header(with_names=True).items():
             fn = getattr(self._dll, name)  # AttributeError if the header and the library disagree
             fn.restype = restype
             fn.argtypes = argtypes
@@ -56,13 +70,23 @@ class _Lib:
                 self._last_error = fn
                 setattr(self, name, fn)
             elif restype is ctypes.c_int and name != 'dx_version':
-                setattr(self, name, self._checked(name, fn))
+                setattr(self, name, self._checked(name, fn, argnames))
             else:
                 setattr(self, name, fn)
 
-    def _checked(self, name, fn):
+    def _checked(self, name, fn, argnames):
+        launches = 'stream' in argnames
+
         def call(*args):
-            rc = fn(*args)
+            if TIMER is not None and launches:
+                import torch
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                rc = fn(*args)
+                b.record()
+                TIMER.append((name, dict(zip(argnames, args)), a, b))
+            else:
+                rc = fn(*args)
             if rc != 0:
                 msg = self._last_error().decode(errors='replace') if self._last_error else ''
                 raise DxError(f'{name} failed (code {rc}): {msg}')
