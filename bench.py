@@ -88,6 +88,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
     ap.add_argument('--kernel-table', default='', help='write the per-kernel roofline table of the last timed step to this JSON file')
+    ap.add_argument('--no-graph', action='store_true', help='issue every launch from Python instead of replaying the two captured HIP graphs')
     ap.add_argument('--no-dropout', action='store_true', help='diagnostic only: the headline metric is measured with dropout on')
     args = ap.parse_args()
 
@@ -109,7 +110,6 @@ def main():
     import ubisoft_laforge_daft_exprt_amd as pkg
     from ubisoft_laforge_daft_exprt_amd import ops
     from ubisoft_laforge_daft_exprt_amd import _lib
-    from ubisoft_laforge_daft_exprt_amd.ddp import GradientReducer
     from ubisoft_laforge_daft_exprt_amd.synth import CONFIGS, synthetic_batch, synthetic_state_dict
 
     pkg.set_precision(args.precision)
@@ -127,30 +127,31 @@ def main():
     cfg['seed'] = cfg['seed'] + 1000 * rank                              # every rank owns different utterances
     cfg['n_speakers'] = n_speakers
     batch = synthetic_batch(**cfg)
-    inputs, targets = model.parse_batch(dev, batch)
-    targets = targets + (inputs[6], inputs[7])
     frames = int(batch[9].sum())
     symbols = int(batch[5].sum())
-    reducer = GradientReducer(model, bucket_mb=16.0, grad_sink=os.environ.get('DX_NO_GRAD_SINK', '') == '')
     pkg.manual_seed(1234 + rank)
-
-    from ubisoft_laforge_daft_exprt_amd.optim import FusedAdam, update_learning_rate
-    opt = FusedAdam(reducer, lr=hp.initial_learning_rate, betas=hp.betas, eps=hp.epsilon, weight_decay=hp.weight_decay,
-                    grad_clip_thresh=hp.grad_clip_thresh)
+    from ubisoft_laforge_daft_exprt_amd.trainer import Trainer
+    # the batch is resident in HBM before the timed region starts (the reference's 14-tuple, device tensors; raw frame prosody
+    # rides along in inputs[6], inputs[7] as train.py:405-419 keeps it for the consistency losses)
+    dev_batch = tuple(t.to(dev) if torch.is_tensor(t) else t for t in batch)
+    for i in (5, 9):
+        dev_batch[i]._dx_host_lengths = batch[i].tolist()
+    trainer = Trainer(model, crit, hp, use_graphs=not args.no_graph)
     ev_bwd = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev_red = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    _orig_finish = trainer.reducer.finish
 
     def step(it, timed_idx=None):
-        reducer.zero_grad()
-        out = model(inputs)
-        total, _terms = crit(out, targets, it)
-        total.backward()
+        # Trainer.train_step: [graph A: zero buckets, forward, loss, backward part 1] -> all-reduce group 0 (async) ->
+        # [graph B: accent-encoder backward] -> all-reduce group 1 -> wait -> fused Adam (clip, LR schedule) -> one-launch re-pack
         if timed_idx is not None:
-            ev_bwd[timed_idx].record()
-        reducer.finish()                          # waits for the bucketed all-reduces that were launched during backward
-        if timed_idx is not None:
-            ev_red[timed_idx].record()
-        opt.step(lr=update_learning_rate(hp, it + 1))   # fused Adam + clip + LR schedule, then ONE launch re-packs every weight
+            def finish():
+                ev_bwd[timed_idx].record()
+                _orig_finish()                    # waits for the bucketed all-reduces
+                ev_red[timed_idx].record()
+            trainer.reducer.finish = finish
+        total, _terms, _norm = trainer.train_step([dev_batch])
+        trainer.reducer.finish = _orig_finish
         return total
 
     for it in range(args.warmup):
@@ -165,12 +166,15 @@ def main():
     host_s = 0.0                                  # time the host spends ENQUEUEING a step (no sync inside): must stay below ms_per_step
     for it in range(args.steps):
         if use_events and it == args.steps - 1:
-            # event bracketing of every launch costs ~10 % of a step, so only the LAST timed step carries it
+            # Per-kernel events need one host call per launch, so the LAST timed step is issued eagerly (not as graph replays) with
+            # every launch bracketed: ~25 % slower than a replayed step, 1 step in args.steps, inside the timed region.
+            trainer.use_graphs = False
             _lib.set_timer(records)
         th = time.perf_counter()
         last = step(args.warmup + it, it)
         host_s += time.perf_counter() - th
     _lib.set_timer(None)
+    trainer.use_graphs = not args.no_graph
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -232,7 +236,7 @@ def main():
                                    + (', dropout OFF (diagnostic)' if args.no_dropout else ', dropout on'),
                        'operands': 'bf16 MFMA operands for Conv1d/Linear GEMMs and attention, fp32 accumulate, 1024-wide hidden tensors and qkv stored bf16'
                                    if args.precision == 'bf16' else 'exact f32 MFMA everywhere',
-                       'parallelism': f'dp{world}'},
+                       'parallelism': f'dp{world}', 'launch': 'eager (one Python call per kernel)' if args.no_graph else 'two captured HIP graphs per step + eager optimiser'},
         }
         result['rccl_ranks'] = dist.get_world_size() if world > 1 else 1
         result['exposed_allreduce_ms_per_step'] = round(exposed_ms, 4)

@@ -11,7 +11,9 @@
  *   - lens[b] (int32, device) = valid rows of batch row b; rows n >= lens[b] are padding
  *   - `stream` is a hipStream_t; all work is enqueued on it, nothing synchronises (graph-capture safe)
  *   - return value: 0 = ok, non-zero = error; dx_last_error() returns the message of the calling thread's last error
- *   - dropout: counter-based (seed, element index); the backward entry points regenerate the mask from the same seed
+ *   - dropout: counter-based (seed, element index); the backward entry points regenerate the mask from the same seed.
+ *     seed_offset (optional device scalar) is added to the seed(s) on the device: a captured HIP graph draws a new dropout
+ *     stream on every replay by bumping that scalar, although the launch arguments are frozen
  */
 #ifndef DAFT_EXPRT_HIP_H
 #define DAFT_EXPRT_HIP_H
@@ -75,9 +77,10 @@ int dx_colsum(const void* X, int ldx, float* out, long rows, int C, int x_bf16, 
 
 /* ---- multi-head attention: model.py:165-186 (nn.MultiheadAttention slow path), called from :255 ------------------- */
 int dx_attention_fwd(const void* qkv, int ld, const int* lens, float* ctx, int ldc, float* lse,
-                     int B, int N, int H, int D, uint64_t seed, float p_drop, int bf16, int qkv_bf16, void* stream);
+                     int B, int N, int H, int D, uint64_t seed, const uint64_t* seed_offset, float p_drop, int bf16, int qkv_bf16,
+                     void* stream);
 int dx_attention_bwd(const void* qkv, int ld, const float* ctx, const float* dctx, int ldc, const float* lse, float* delta,
-                     const int* lens, void* dqkv, int ldg, int B, int N, int H, int D, uint64_t seed, float p_drop, int bf16,
+                     const int* lens, void* dqkv, int ldg, int B, int N, int H, int D, uint64_t seed, const uint64_t* seed_offset, float p_drop, int bf16,
                      int qkv_bf16, int dqkv_bf16, void* stream);
 /* bf16 = 1: QK^T / PV (and the five backward products) on v_mfma_f32_16x16x32_bf16, softmax and accumulation in fp32;
  * qkv_bf16 / dqkv_bf16 = 1: the in-projection output / its gradient are stored as bf16 (ld in elements) */
@@ -88,11 +91,13 @@ int dx_attention_bwd(const void* qkv, int ld, const float* ctx, const float* dct
  * unmasked prenet LayerNorms whose rows inside the conv halo are still needed */
 int dx_ln_fwd(void* a, const void* res, const float* w, const float* bias, const float* film, int ld_film,
               const int* lens, int halo, void* y, float* mean, float* rstd, int B, int N, int C,
-              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, int io_bf16, void* y_bf16_copy, void* stream);
+              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, const uint64_t* seed_offset, int io_bf16, void* y_bf16_copy,
+              void* stream);
 int dx_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* w, const float* bias,
               const float* film, int ld_film, const int* lens, int halo, void* dz, void* da, float* dw, float* dbias,
               float* dfilm, int ld_dfilm, int B, int N, int C, int relu_mask,
-              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, int io_bf16, void* dg_bf16_copy, void* stream);
+              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, const uint64_t* seed_offset, int io_bf16, void* dg_bf16_copy,
+              void* stream);
 /* y_bf16_copy / dg_bf16_copy (optional, C = 128): a second, bf16 copy of y / of the gradient that feeds the GEMM backward.  The
  * next GEMM would round its fp32 operand to bf16 while staging anyway, so results are bit-identical and the operand costs half the bytes.
  * io_bf16 = 1 (C = 1024 only): a / res / y and dy / z / dz / da are stored as bf16; statistics and parameter gradients stay fp32 */

@@ -165,3 +165,62 @@ def test_optimizer_state_round_trips_with_torch_adam_layout(oracle_run):
     assert abs(float(l1) - float(l2)) <= 1e-6 * abs(float(l1))
     for (k, a), (_, b) in zip(trainer.model.named_parameters(), t2.model.named_parameters()):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), k
+
+
+def test_graph_replay_matches_eager_two_phase_step():
+    """The captured two-graph step (trainer.Trainer(use_graphs=True)) against the same step issued eagerly: identical loss and
+    parameter trajectory at dropout p = 0, over several batches of two alternating padded shapes (so both graph sets are replayed
+    after other work has run); with dropout on, replays of one shape draw different masks (device-side seed offset)."""
+    import ubisoft_laforge_daft_exprt_amd as pkg
+    from ubisoft_laforge_daft_exprt_amd.synth import synthetic_batch
+    from ubisoft_laforge_daft_exprt_amd.trainer import Trainer
+    hp = helpers.golden_hparams(initial_learning_rate=2e-4, max_learning_rate=2e-3, warmup_steps=10, grad_clip_thresh=5.0)
+    shapes = [dict(sym_lengths=[30, 28, 21, 9]), dict(sym_lengths=[44, 40, 12])]
+    batches = []
+    for s in range(8):
+        kw = shapes[s % 2]
+        g = torch.Generator().manual_seed(900 + s)
+        L = max(kw['sym_lengths'])
+        dur = torch.randint(2, 7, (len(kw['sym_lengths']), L), generator=g)
+        dur[0, :kw['sym_lengths'][0]] = 5                               # row 0 is the longest on both axes: T_max fixed per shape
+        batches.append(synthetic_batch(len(kw['sym_lengths']), (1, L), seed=950 + s, n_speakers=3, sym_lengths=kw['sym_lengths'], durations_int=dur))
+    runs = {}
+    for mode in (False, True):
+        pkg.set_precision('bf16')
+        try:
+            model = pkg.DaftExprt(hp).to(DEV)
+            model.load_state_dict(helpers.golden_state_dict(), strict=True)
+            crit = pkg.DaftExprtLoss(DEV, hp)
+            crit.load_pitch_predictor(helpers.golden_pitch_predictor_state_dict())
+        finally:
+            pkg.set_precision('f32')
+        t = Trainer(model, crit, hp, use_graphs=mode)
+        losses, l1 = [], []
+        for b in batches:
+            loss, terms, _ = t.train_step([b])
+            losses.append(float(loss))
+            l1.append(terms[0]['mel_spec_l1_loss'])
+        runs[mode] = (losses, l1, {k: p.detach().clone() for k, p in model.named_parameters()})
+        if mode:
+            assert len(t.graphs) == 2 and all(g.hits == 4 for g in t.graphs.values())
+    (le, l1e, pe), (lg, l1g, pg) = runs[False], runs[True]
+    print('eager', le, 'graph', lg)
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 1e-5 * abs(a), (le, lg)                      # same kernels, same order: only atomics reorder
+    for a, b in zip(l1e, l1g):
+        assert abs(a - b) <= 1e-5 * abs(a)
+    for k in pe:
+        assert torch.allclose(pe[k], pg[k], rtol=1e-3, atol=1e-5), k
+    # dropout on: the seed offset advances inside graph A, so two replays of ONE graph on the SAME batch differ
+    hp_d = pkg.HyperParams(n_speakers=3)
+    pkg.set_precision('bf16')
+    try:
+        model = pkg.DaftExprt(hp_d).to(DEV)
+        model.load_state_dict(helpers.golden_state_dict(), strict=True)
+        crit = pkg.DaftExprtLoss(DEV, hp_d)
+        crit.load_pitch_predictor(helpers.golden_pitch_predictor_state_dict())
+    finally:
+        pkg.set_precision('f32')
+    t = Trainer(model, crit, hp_d.clone(initial_learning_rate=0.0, max_learning_rate=0.0), use_graphs=True)   # lr 0: weights stay put
+    vals = [float(t.train_step([batches[0]])[0]) for _ in range(3)]
+    assert len(t.graphs) == 1 and len({round(v, 6) for v in vals}) == 3, vals

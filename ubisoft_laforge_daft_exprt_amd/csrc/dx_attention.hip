@@ -32,6 +32,7 @@ struct AttnArgs {
   float* lse;                      // [B][H][N]
   int B, N, H, D;
   uint64_t seed; uint32_t thresh; float inv_keep;
+  const uint64_t* seed_offset;     // optional device scalar added to `seed` (captured HIP graphs: a new dropout stream per replay)
 };
 
 __device__ __forceinline__ f32x4 mma4(const float4& a, const float4& b, f32x4 c) {
@@ -59,7 +60,9 @@ __device__ __forceinline__ uint64_t drop_index(int bh, int N, int q, int key) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a_) {
+  AttnArgs a = a_;
+  if (a.seed_offset) a.seed += *a.seed_offset;
   __shared__ __attribute__((aligned(16))) float Ks[64 * TLD];
   __shared__ __attribute__((aligned(16))) float Vs[64 * TLD];
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
@@ -184,12 +187,15 @@ struct AttnBwdArgs {
   uint64_t seed; uint32_t thresh; float inv_keep;
   const float* ctx;                       // [B*N][ldc]: the bf16 dQ kernel computes delta itself (and stores it for dK/dV)
   float* delta_out;
+  const uint64_t* seed_offset;
 };
 
 // ------------------------------------------------------------------------------------------------
 // dQ: same geometry as the forward
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a_) {
+  AttnBwdArgs a = a_;
+  if (a.seed_offset) a.seed += *a.seed_offset;
   __shared__ __attribute__((aligned(16))) float Ks[64 * TLD];
   __shared__ __attribute__((aligned(16))) float Vs[64 * TLD];
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
@@ -273,7 +279,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
 // ------------------------------------------------------------------------------------------------
 // dK, dV: workgroup = 64 keys of one (b, h); wave = 16 keys; loop over 64-query tiles
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs a_) {
+  AttnBwdArgs a = a_;
+  if (a.seed_offset) a.seed += *a.seed_offset;
   __shared__ __attribute__((aligned(16))) float Qs[64 * TLD];
   __shared__ __attribute__((aligned(16))) float Gs[64 * TLD];
   __shared__ float lse_s[64], delta_s[64];
@@ -478,7 +486,9 @@ __device__ __forceinline__ void store4(__bf16* p, float a, float b, float c, flo
 #define DX_MFMA_BF16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A), (B), (C), 0, 0, 0)
 
 template <typename QT>
-__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a_) {
+  AttnArgs a = a_;
+  if (a.seed_offset) a.seed += *a.seed_offset;
   __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * 128];
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
@@ -577,7 +587,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a)
 }
 
 template <typename QT, typename OT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdArgs a_) {
+  AttnBwdArgs a = a_;
+  if (a.seed_offset) a.seed += *a.seed_offset;
   __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * 128];
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
@@ -675,7 +687,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
 }
 
 template <typename QT, typename OT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwdArgs a_) {
+  AttnBwdArgs a = a_;
+  if (a.seed_offset) a.seed += *a.seed_offset;
   __shared__ __attribute__((aligned(16))) unsigned char Qs[64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char Gs[64 * 128];
   __shared__ float lse_s[64], delta_s[64];
@@ -819,13 +833,13 @@ int check_common(const char* who, const void* qkv, int ld, int B, int N, int H, 
 extern "C" {
 
 int dx_attention_fwd(const void* qkvv, int ld, const int* lens, float* ctx, int ldc, float* lse,
-                     int B, int N, int H, int D, uint64_t seed, float p_drop, int bf16, int qkv_bf16, void* stream) {
+                     int B, int N, int H, int D, uint64_t seed, const uint64_t* seed_offset, float p_drop, int bf16, int qkv_bf16, void* stream) {
   const float* qkv = (const float*)qkvv;
   if (int rc = check_common("dx_attention_fwd", qkv, ld, B, N, H, D)) return rc;
   DX_REQUIRE(!qkv_bf16 || (bf16 && (ld % 8) == 0), "dx_attention_fwd: bf16-stored qkv needs bf16 mode and ld %% 8 == 0");
   DX_REQUIRE(lens && ctx && lse && ldc >= D && (ldc % 4) == 0 && ((uintptr_t)ctx % 16) == 0, "dx_attention_fwd: bad output arguments");
   DX_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "dx_attention_fwd: dropout p out of range");
-  AttnArgs a{qkv, ld, lens, ctx, ldc, lse, B, N, H, D, seed, (uint32_t)lrintf(p_drop * 65536.f), 1.f / (1.f - p_drop)};
+  AttnArgs a{qkv, ld, lens, ctx, ldc, lse, B, N, H, D, seed, (uint32_t)lrintf(p_drop * 65536.f), 1.f / (1.f - p_drop), seed_offset};
   hipStream_t s = (hipStream_t)stream;
   dx_prof_begin(DX_PROF_ATTN_FWD, s);
   if (bf16 && qkv_bf16) hipLaunchKernelGGL(attn_fwd_bf16_kernel<__bf16>, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
@@ -838,7 +852,7 @@ int dx_attention_fwd(const void* qkvv, int ld, const int* lens, float* ctx, int 
 
 // dqkv (all three thirds, every row) from dctx; `delta` is scratch [B][H][N]
 int dx_attention_bwd(const void* qkvv, int ld, const float* ctx, const float* dctx, int ldc, const float* lse, float* delta,
-                     const int* lens, void* dqkvv, int ldg, int B, int N, int H, int D, uint64_t seed, float p_drop, int bf16,
+                     const int* lens, void* dqkvv, int ldg, int B, int N, int H, int D, uint64_t seed, const uint64_t* seed_offset, float p_drop, int bf16,
                      int qkv_bf16, int dqkv_bf16, void* stream) {
   const float* qkv = (const float*)qkvv; float* dqkv = (float*)dqkvv;
   if (int rc = check_common("dx_attention_bwd", qkv, ld, B, N, H, D)) return rc;
@@ -851,7 +865,7 @@ int dx_attention_bwd(const void* qkvv, int ld, const float* ctx, const float* dc
   const long items = (long)B * N * H;
   if (!bf16)                                       // the bf16 dQ kernel computes delta on the fly and leaves it for dK/dV
     hipLaunchKernelGGL(attn_delta_kernel, dim3((int)std::min<long>((items + 3) / 4, 8192)), dim3(256), 0, s, dctx, ctx, ldc, delta, B, N, H);
-  AttnBwdArgs a{qkv, ld, dctx, ldc, lse, delta, lens, dqkv, ldg, B, N, H, D, seed, (uint32_t)lrintf(p_drop * 65536.f), 1.f / (1.f - p_drop), ctx, delta};
+  AttnBwdArgs a{qkv, ld, dctx, ldc, lse, delta, lens, dqkv, ldg, B, N, H, D, seed, (uint32_t)lrintf(p_drop * 65536.f), 1.f / (1.f - p_drop), ctx, delta, seed_offset};
   dx_prof_begin(DX_PROF_ATTN_BWD, s);
   if (bf16) {
     const dim3 grid(dx_cdiv(N, 64), H, B);

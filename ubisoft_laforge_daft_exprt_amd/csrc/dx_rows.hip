@@ -29,6 +29,7 @@ struct LnArgs {
   int B, N;
   uint64_t seed_pre; uint32_t thresh_pre; float inv_keep_pre;     // dropout on `a` (thresh 0 = off)
   uint64_t seed_post; uint32_t thresh_post; float inv_keep_post;  // dropout on LN output
+  const uint64_t* seed_offset;                                    // optional device scalar added to both seeds (captured HIP graphs)
 };
 
 // Row layout in a wave: LPR lanes share one row and a wave walks 64/LPR rows at once.  C = 128 rows are only 512 bytes,
@@ -87,7 +88,9 @@ template <int C> __device__ __forceinline__ float row_sum(float v) {
 }
 
 template <int C, typename IO>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a) {
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a_) {
+  LnArgs a = a_;
+  if (a.seed_offset) { const uint64_t o = *a.seed_offset; a.seed_pre += o; a.seed_post += o; }
   constexpr int E = RowVec<C>::E, LPR = RowVec<C>::LPR, RPW = RowVec<C>::RPW;
   IO* const A = reinterpret_cast<IO*>(a.a);
   const IO* const R = reinterpret_cast<const IO*>(a.res);
@@ -161,11 +164,14 @@ struct LnBwdArgs {
   int relu_mask;       // multiply dz by (z > 0): ReLU sits right before the LayerNorm (prenet)
   uint64_t seed_pre; uint32_t thresh_pre; float inv_keep_pre;
   uint64_t seed_post; uint32_t thresh_post; float inv_keep_post;
+  const uint64_t* seed_offset;
 };
 
 // grid: (blocks per batch row, B); each block walks rows of ONE batch row so FiLM gradients reduce per b.
 template <int C, typename IO, bool FILM>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a) {
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a_) {
+  LnBwdArgs a = a_;
+  if (a.seed_offset) { const uint64_t o = *a.seed_offset; a.seed_pre += o; a.seed_post += o; }
   constexpr int E = RowVec<C>::E, LPR = RowVec<C>::LPR, RPW = RowVec<C>::RPW;
   const IO* const DY = reinterpret_cast<const IO*>(a.dy);
   const IO* const Z = reinterpret_cast<const IO*>(a.z);
@@ -546,7 +552,8 @@ extern "C" {
 
 int dx_ln_fwd(void* av, const void* resv, const float* w, const float* bias, const float* film, int ld_film,
               const int* lens, int halo, void* yv, float* mean, float* rstd, int B, int N, int C,
-              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, int io_bf16, void* y_bf16_copy, void* stream) {
+              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, const uint64_t* seed_offset, int io_bf16, void* y_bf16_copy,
+              void* stream) {
   float* a = (float*)av; const float* res = (const float*)resv; float* y = (float*)yv;
   DX_REQUIRE(!y_bf16_copy || (C == 128 && !io_bf16), "dx_ln_fwd: the bf16 shadow output is for fp32 rows with C = 128");
   DX_REQUIRE(a && w && bias && y && mean && rstd, "dx_ln_fwd: null pointer");
@@ -557,7 +564,7 @@ int dx_ln_fwd(void* av, const void* resv, const float* w, const float* bias, con
   DX_REQUIRE(!film || ld_film >= 2 * C, "dx_ln_fwd: ld_film too small");
   LnArgs k{a, res, w, bias, film, ld_film, lens, halo, y, (__bf16*)y_bf16_copy, mean, rstd, B, N,
            seed_pre, (uint32_t)lrintf(p_pre * 65536.f), 1.f / (1.f - p_pre),
-           seed_post, (uint32_t)lrintf(p_post * 65536.f), 1.f / (1.f - p_post)};
+           seed_post, (uint32_t)lrintf(p_post * 65536.f), 1.f / (1.f - p_post), seed_offset};
   hipStream_t s = (hipStream_t)stream;
   dx_prof_begin(DX_PROF_ROWS, s);
   const int grid = row_grid((long)B * N);
@@ -572,7 +579,8 @@ int dx_ln_fwd(void* av, const void* resv, const float* w, const float* bias, con
 int dx_ln_bwd(const void* dyv, const void* zv, const float* mean, const float* rstd, const float* w, const float* bias,
               const float* film, int ld_film, const int* lens, int halo, void* dzv, void* dav, float* dw, float* dbias,
               float* dfilm, int ld_dfilm, int B, int N, int C, int relu_mask,
-              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, int io_bf16, void* dg_bf16_copy, void* stream) {
+              uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, const uint64_t* seed_offset, int io_bf16, void* dg_bf16_copy,
+              void* stream) {
   const float* dy = (const float*)dyv;
   DX_REQUIRE(!dg_bf16_copy || (C == 128 && !io_bf16), "dx_ln_bwd: the bf16 shadow output is for fp32 rows with C = 128"); const float* z = (const float*)zv; float* dz = (float*)dzv; float* da = (float*)dav;
   DX_REQUIRE(!io_bf16 || C == 1024, "dx_ln_bwd: bf16 rows are supported for C = 1024 only");
@@ -582,7 +590,7 @@ int dx_ln_bwd(const void* dyv, const void* zv, const float* mean, const float* r
   const int rpb = 64;
   LnBwdArgs k{dy, z, mean, rstd, w, bias, film, ld_film, lens, halo, dz, da, (__bf16*)dg_bf16_copy, dw, dbias, dfilm, ld_dfilm, B, N, rpb, relu_mask,
               seed_pre, (uint32_t)lrintf(p_pre * 65536.f), 1.f / (1.f - p_pre),
-              seed_post, (uint32_t)lrintf(p_post * 65536.f), 1.f / (1.f - p_post)};
+              seed_post, (uint32_t)lrintf(p_post * 65536.f), 1.f / (1.f - p_post), seed_offset};
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(dx_cdiv(N, rpb), B);
   dx_prof_begin(DX_PROF_ROWS, s);

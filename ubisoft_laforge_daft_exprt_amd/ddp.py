@@ -28,9 +28,11 @@ import torch.distributed as dist
 
 class GradientReducer:
     def __init__(self, module: torch.nn.Module, bucket_mb: float = 16.0, process_group=None, grad_sink: bool = False,
-                 broadcast_parameters: bool = True):
+                 broadcast_parameters: bool = True, group_of=None):
         """``grad_sink=True``: the HIP backward kernels accumulate straight into the bucket views (the model's ``runtime.sink``);
-        requires ``zero_grad()`` of THIS object before every step."""
+        requires ``zero_grad()`` of THIS object before every step.
+        ``group_of(parameter name) -> int``: parameters of different groups never share a bucket (``bucket_group[i]`` is bucket
+        i's group), so a caller that finishes backward group by group can exchange a group as soon as it is complete."""
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -39,19 +41,24 @@ class GradientReducer:
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
                     dist.broadcast(t.data, src=src, group=process_group)
-        params = [p for p in module.parameters() if p.requires_grad]
-        params.reverse()
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        named.reverse()
+        params = [p for _, p in named]
         cap = int(bucket_mb * 1024 * 1024 / 4)
-        self.buckets = []
-        cur, cur_n = [], 0
-        for p in params:
-            if cur and cur_n + p.numel() > cap:
+        self.buckets, self.bucket_group = [], []
+        cur, cur_n, cur_g = [], 0, None
+        for n, p in named:
+            gid = group_of(n) if group_of is not None else 0
+            if cur and (cur_n + p.numel() > cap or gid != cur_g):
                 self.buckets.append(cur)
+                self.bucket_group.append(cur_g)
                 cur, cur_n = [], 0
             cur.append(p)
             cur_n += p.numel()
+            cur_g = gid
         if cur:
             self.buckets.append(cur)
+            self.bucket_group.append(cur_g)
         self.flat, self.bucket_of = [], {}
         for bi, bucket in enumerate(self.buckets):
             n = sum(p.numel() for p in bucket)
@@ -63,6 +70,7 @@ class GradientReducer:
                 self.bucket_of[p] = bi
             self.flat.append(flat)
         self.pending = [len(b) for b in self.buckets]
+        self.launched = set()                     # buckets whose exchange has been launched explicitly in this step
         self.works = []
         self.sync = True
         self.hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
@@ -91,6 +99,7 @@ class GradientReducer:
         """Keeps the grad views alive (set_to_none would detach them from the buckets)."""
         for flat in self.flat:
             flat.zero_()
+        self.launched.clear()
         self.pending = [len(b) for b in self.buckets]
 
     @contextlib.contextmanager
@@ -98,7 +107,7 @@ class GradientReducer:
         """One micro-batch's backward inside a gradient-accumulation step.  ``sync=False``: its gradients are only summed
         into the buckets; ``sync=True`` (the last micro-batch): completed buckets are all-reduced as usual."""
         self._check_balanced()
-        self.pending = [len(b) for b in self.buckets]
+        self.pending = [0 if bi in self.launched else len(b) for bi, b in enumerate(self.buckets)]
         self.sync = bool(sync)
         try:
             yield self
@@ -120,7 +129,20 @@ class GradientReducer:
             if op == dist.ReduceOp.SUM and self.world > 1:
                 self.flat[bi].div_(self.world)
         self.works = []
+        self.launched.clear()
         self.pending = [len(b) for b in self.buckets]
+
+    def launch_group(self, gid=None):
+        """Explicit asynchronous exchange of the buckets of group ``gid`` (all buckets if None): for callers whose backward does not
+        run Python hooks -- a replayed HIP graph.  The collectives run on RCCL's stream behind everything enqueued on the compute
+        stream so far; ``finish()`` waits for them."""
+        for bi, flat in enumerate(self.flat):
+            if gid is None or self.bucket_group[bi] == gid:
+                self.pending[bi] = 0
+                self.launched.add(bi)
+                if self.world > 1:
+                    op = self._reduce_op()
+                    self.works.append((dist.all_reduce(flat, op=op, group=self.group, async_op=True), bi, op))
 
     def remove(self):
         for h in self.hooks:

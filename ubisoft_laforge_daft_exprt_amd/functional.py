@@ -102,7 +102,9 @@ class PaddedLinear:
         # (``data_ptr``: optim.FusedAdam moves parameters into flat buckets) and raw-pointer writes by ``dx_adam_step`` (the pack
         # epoch, which the optimiser bumps after every step).
         key = (self.weight._version, self.bias._version, self.weight.data_ptr(), self.bias.data_ptr(), self.rt.pack_epoch)
-        if key != self._key:
+        # under HIP-graph capture the refresh is recorded unconditionally: this Python check does not run on replay, and the
+        # optimiser rewrites the parameter between replays
+        if key != self._key or (self.wpad is not None and self.wpad.is_cuda and torch.cuda.is_current_stream_capturing()):
             w = self.weight.detach()
             if self.wpad is None or self.wpad.device != w.device:
                 self.wpad = torch.zeros(self.cout4, w.shape[1], dtype=w.dtype, device=w.device)
@@ -152,10 +154,11 @@ class FFTBlockFn(torch.autograd.Function):
         prec = rt.precision                        # captured here, used by the backward (never re-read)
         hd = ops.hidden_dtype(prec)
         qkv = ops.conv_gemm(x, packs['in'], in_b, lens=L, halo=0, out_dtype=hd, prec=prec)   # bf16 mode: attention reads bf16 q/k/v
-        att, lse = ops.attention_fwd(qkv, lens.i32, heads, s_attn, p_attn, prec=prec)
+        so = rt.seed_offset                        # device scalar added to the seeds (graph replays), or None
+        att, lse = ops.attention_fwd(qkv, lens.i32, heads, s_attn, p_attn, prec=prec, seed_offset=so)
         z1 = ops.conv_gemm(att, packs['out'], out_b, lens=L, halo=0, prec=prec)
         sh = ops.gemm_shadow(prec)                 # bf16 mode: GEMM operands also exist as bf16 copies written by their producers
-        ln1 = ops.ln_fwd(z1, x, ln1_w, ln1_b, None, lens.i32, seed_pre=s_ln1, p_pre=p_attn, shadow=sh)
+        ln1 = ops.ln_fwd(z1, x, ln1_w, ln1_b, None, lens.i32, seed_pre=s_ln1, p_pre=p_attn, shadow=sh, seed_offset=so)
         y1, mean1, rstd1 = ln1[:3]
         y1g = ln1[3] if sh else y1                 # the copy the GEMMs read
         fused = ops.ff_pair_applies(y1g, packs['c1'], packs['c2'], prec)
@@ -164,11 +167,11 @@ class FFTBlockFn(torch.autograd.Function):
         else:
             h = ops.conv_gemm(y1g, packs['c1'], c1_b, relu=True, lens=L, halo=1, out_dtype=hd, prec=prec)   # conv2 reads one row past the end
             z2 = ops.conv_gemm(h, packs['c2'], c2_b, lens=L, halo=0, prec=prec)
-        y2, mean2, rstd2 = ops.ln_fwd(z2, y1, ln2_w, ln2_b, film, lens.i32, seed_pre=s_ln2, p_pre=p_conv)
+        y2, mean2, rstd2 = ops.ln_fwd(z2, y1, ln2_w, ln2_b, film, lens.i32, seed_pre=s_ln2, p_pre=p_conv, seed_offset=so)
         ctx.save_for_backward(x, film, qkv, att, lse, z1, mean1, rstd1, y1g, h, z2, mean2, rstd2, ln1_w, ln1_b, ln2_w, ln2_b)
         ctx.lens, ctx.packs, ctx.heads = lens, packs, heads
         ctx.drop = (p_attn, p_conv, s_attn, s_ln1, s_ln2)
-        ctx.prec, ctx.sink, ctx.fused = prec, rt.sink, fused
+        ctx.prec, ctx.sink, ctx.fused, ctx.seed_offset = prec, rt.sink, fused, so
         return y2
 
     @staticmethod
@@ -187,7 +190,8 @@ class FFTBlockFn(torch.autograd.Function):
         sk = {k: _sink(v, ctx.sink) for k, v in P.items()}
         g = sk.get
         sh = ops.gemm_shadow(prec)
-        r2 = ops.ln_bwd(dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, L, want_da=p_conv > 0, seed_pre=s_ln2,
+        so = ctx.seed_offset
+        r2 = ops.ln_bwd(dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, L, want_da=p_conv > 0, seed_pre=s_ln2, seed_offset=so,
                         p_pre=p_conv, arena=arena, w_sink=g('ln2_w'), b_sink=g('ln2_b'), shadow=sh)
         dz2, da2, dln2_w, dln2_b, dfilm = r2[:5]
         dff = r2[5] if sh else (da2 if da2 is not None else dz2)      # gradient w.r.t. the conv2 output, as the GEMMs read it
@@ -198,13 +202,13 @@ class FFTBlockFn(torch.autograd.Function):
             dh = ops.conv_gemm(dff, packs['c2'], None, transpose=True, relu_aux=h, lens=L, halo=1, out_dtype=h.dtype, prec=prec)
             dy1 = ops.conv_gemm(dh, packs['c1'], None, transpose=True, out=dz2, accumulate=True, lens=L, halo=0, prec=prec)  # + residual branch
         dc1_w, dc1_b = ops.conv_wgrad(dh, y1, packs['c1'], L, 1, arena=arena, w_sink=g('c1_w'), b_sink=g('c1_b'), prec=prec)
-        r1 = ops.ln_bwd(dy1, z1, mean1, rstd1, ln1_w, ln1_b, None, L, want_da=p_attn > 0, seed_pre=s_ln1,
+        r1 = ops.ln_bwd(dy1, z1, mean1, rstd1, ln1_w, ln1_b, None, L, want_da=p_attn > 0, seed_pre=s_ln1, seed_offset=so,
                         p_pre=p_attn, arena=arena, w_sink=g('ln1_w'), b_sink=g('ln1_b'), shadow=sh)
         dz1, da1, dln1_w, dln1_b = r1[:4]
         dproj = r1[5] if sh else (da1 if da1 is not None else dz1)
         dout_w, dout_b = ops.conv_wgrad(dproj, att, packs['out'], L, 0, arena=arena, w_sink=g('out_w'), b_sink=g('out_b'), prec=prec)
         datt = ops.conv_gemm(dproj, packs['out'], None, transpose=True, lens=L, halo=0, prec=prec)
-        dqkv = ops.attention_bwd(qkv, att, datt, lse, L, ctx.heads, s_attn, p_attn, out_dtype=qkv.dtype, prec=prec)
+        dqkv = ops.attention_bwd(qkv, att, datt, lse, L, ctx.heads, s_attn, p_attn, out_dtype=qkv.dtype, prec=prec, seed_offset=so)
         din_w, din_b = ops.conv_wgrad(dqkv, x, packs['in'], L, 0, arena=arena, w_sink=g('in_w'), b_sink=g('in_b'), prec=prec)
         dx = ops.conv_gemm(dqkv, packs['in'], None, transpose=True, out=dz1, accumulate=True, lens=L, halo=0, prec=prec)  # + residual branch
         return (dx, dfilm, None, None, None, None,
@@ -225,24 +229,26 @@ class AccentFrontFn(torch.autograd.Function):
         rt = packs['p0'].rt
         prec = rt.precision
         hd = ops.hidden_dtype(prec)                                           # 1024-wide tensors: bf16 in bf16 operand mode
+        so = rt.seed_offset
         h0 = ops.conv_gemm(x0, packs['p0'], c0_b, relu=True, lens=L, halo=2, out_dtype=hd, prec=prec)   # three stacked k=3 convs: halos 2, 1, 0
-        y0, m0, r0 = ops.ln_fwd(h0, None, l0_w, l0_b, None, L, seed_post=seeds[0], p_post=p, halo=2)
+        y0, m0, r0 = ops.ln_fwd(h0, None, l0_w, l0_b, None, L, seed_post=seeds[0], p_post=p, halo=2, seed_offset=so)
         h1 = ops.conv_gemm(y0, packs['p1'], c1_b, relu=True, lens=L, halo=1, out_dtype=hd, prec=prec)
-        y1, m1, r1 = ops.ln_fwd(h1, None, l1_w, l1_b, None, L, seed_post=seeds[1], p_post=p, halo=1)
+        y1, m1, r1 = ops.ln_fwd(h1, None, l1_w, l1_b, None, L, seed_post=seeds[1], p_post=p, halo=1, seed_offset=so)
         h2 = ops.conv_gemm(y1, packs['p2'], c2_b, relu=True, lens=L, halo=0, prec=prec)
-        y2, m2, r2 = ops.ln_fwd(h2, None, l2_w, l2_b, None, L, seed_post=seeds[2], p_post=p, halo=0)
+        y2, m2, r2 = ops.ln_fwd(h2, None, l2_w, l2_b, None, L, seed_post=seeds[2], p_post=p, halo=0, seed_offset=so)
         energy, pitch = energy.contiguous(), pitch.contiguous()
         out = ops.accent_sum(y2, energy, pitch, we, be, wp, bp, pe, lens.i32)
         ctx.save_for_backward(x0, h0, m0, r0, y0, h1, m1, r1, y1, h2, m2, r2, energy, pitch, l0_w, l0_b, l1_w, l1_b, l2_w, l2_b)
         ctx.lens, ctx.packs, ctx.p, ctx.seeds = lens, packs, p, seeds
         ctx.emb_params = (we, be, wp, bp)
-        ctx.prec, ctx.sink = prec, rt.sink
+        ctx.prec, ctx.sink, ctx.seed_offset = prec, rt.sink, so
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x0, h0, m0, r0, y0, h1, m1, r1, y1, h2, m2, r2, energy, pitch, l0_w, l0_b, l1_w, l1_b, l2_w, l2_b = ctx.saved_tensors
         lens, packs, p, seeds = ctx.lens, ctx.packs, ctx.p, ctx.seeds
+        so = ctx.seed_offset
         dout = ops.mask_rows(dout.contiguous(), lens.i32)
         dwe, dbe, dwp, dbp = ops.scalar_conv_wgrad(dout, energy, pitch, lens.i32, sinks=tuple(_sink(q, ctx.sink) for q in ctx.emb_params))
         L = lens.i32
@@ -250,15 +256,15 @@ class AccentFrontFn(torch.autograd.Function):
         prec = ctx.prec
         sk = {k: _sink(v, ctx.sink) for k, v in P.items()}
         g = sk.get
-        dz2, _, dl2_w, dl2_b, _ = ops.ln_bwd(dout, h2, m2, r2, l2_w, l2_b, None, L, relu_mask=True, seed_post=seeds[2], p_post=p,
+        dz2, _, dl2_w, dl2_b, _ = ops.ln_bwd(dout, h2, m2, r2, l2_w, l2_b, None, L, relu_mask=True, seed_post=seeds[2], p_post=p, seed_offset=so,
                                               w_sink=g('l2_w'), b_sink=g('l2_b'), halo=0)
         dc2_w, dc2_b = ops.conv_wgrad(dz2, y1, packs['p2'], L, 0, w_sink=g('c2_w'), b_sink=g('c2_b'), prec=prec)
         dy1 = ops.conv_gemm(dz2, packs['p2'], None, transpose=True, lens=L, halo=1, out_dtype=h1.dtype, prec=prec)
-        dz1, _, dl1_w, dl1_b, _ = ops.ln_bwd(dy1, h1, m1, r1, l1_w, l1_b, None, L, relu_mask=True, seed_post=seeds[1], p_post=p,
+        dz1, _, dl1_w, dl1_b, _ = ops.ln_bwd(dy1, h1, m1, r1, l1_w, l1_b, None, L, relu_mask=True, seed_post=seeds[1], p_post=p, seed_offset=so,
                                               w_sink=g('l1_w'), b_sink=g('l1_b'), halo=1)
         dc1_w, dc1_b = ops.conv_wgrad(dz1, y0, packs['p1'], L, 1, w_sink=g('c1_w'), b_sink=g('c1_b'), prec=prec)
         dy0 = ops.conv_gemm(dz1, packs['p1'], None, transpose=True, lens=L, halo=2, out_dtype=h0.dtype, prec=prec)
-        dz0, _, dl0_w, dl0_b, _ = ops.ln_bwd(dy0, h0, m0, r0, l0_w, l0_b, None, L, relu_mask=True, seed_post=seeds[0], p_post=p,
+        dz0, _, dl0_w, dl0_b, _ = ops.ln_bwd(dy0, h0, m0, r0, l0_w, l0_b, None, L, relu_mask=True, seed_post=seeds[0], p_post=p, seed_offset=so,
                                               w_sink=g('l0_w'), b_sink=g('l0_b'), halo=2)
         dc0_w, dc0_b = ops.conv_wgrad(dz0, x0, packs['p0'], L, 2, w_sink=g('c0_w'), b_sink=g('c0_b'), prec=prec)
         return (None, None, None, None, None, None, None, None,

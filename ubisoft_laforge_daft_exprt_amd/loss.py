@@ -80,7 +80,7 @@ class _LossFn(torch.autograd.Function):
         if speaker_preds is not None:
             ce, dlogits = ops.cross_entropy(speaker_preds.contiguous(), speaker_ids.contiguous())
             terms[1:2] = ce
-            terms[0:1] = cfg['spk_weight'] * ce
+            terms[0:1] = cfg['spk_weight'] * ce               # python float, or a device scalar (captured graphs: updated per replay)
             d_spk = dlogits * cfg['spk_weight']
         if post_multipliers is not None:
             nrm = torch.linalg.vector_norm(post_multipliers.detach())      # 16 numbers
@@ -93,8 +93,11 @@ class _LossFn(torch.autograd.Function):
         des, c_e = None, 0.0
         if cfg['ecw'] > 0:
             des, esum = ops.energy_diff(ep, et, lens.i32)
-            terms[5:6] = esum / float(lens.total)
-            c_e = cfg['ecw'] / float(lens.total)
+            # 1 / sum of lengths as a DEVICE value: a host float here would be frozen into a captured graph
+            inv_total = 1.0 / lens.i32.sum().to(torch.float32)
+            terms[5:6] = esum * inv_total
+            des = des * inv_total
+            c_e = cfg['ecw']
         dmel = ops.mel_grad(mel_pred, mel_target, ep, des, lens.i32, cfg['msw'] / (M * B), cfg['msw'] / (M * B), c_e)
         if pitch_layers is not None and frames_pitch is not None and cfg['pcw'] > 0:
             # frozen predictor on the predicted mel, channels-last; gradient flows through it to the mel only
@@ -177,7 +180,10 @@ class DaftExprtLoss(nn.Module):
             raise RuntimeError('DaftExprtLoss (MI355X build) runs on the GPU only; there is no CPU path')
         lens = output_lengths if isinstance(output_lengths, Lengths) else Lengths(output_lengths, host=getattr(output_lengths, '_dx_host_lengths', None))
         pm = post_multipliers if (self.post_mult_weight != 0.0 and torch.is_tensor(post_multipliers)) else None
-        cfg = {'spk_weight': self.update_adversarial_weight(iteration), 'pmw': self.post_mult_weight, 'msw': self.mel_spec_weight,
+        # ``iteration``: the step number, or -- from a trainer that replays captured graphs -- the adversarial weight itself as a
+        # device scalar it updates before every replay
+        spk_weight = iteration if torch.is_tensor(iteration) else self.update_adversarial_weight(iteration)
+        cfg = {'spk_weight': spk_weight, 'pmw': self.post_mult_weight, 'msw': self.mel_spec_weight,
                'ecw': self.energy_consistency_weight, 'pcw': self.pitch_consistency_weight if self.pitch_layers is not None else 0.0}
         total, terms = _LossFn.apply(mel_preds, speaker_preds, pm, mel_targets, speaker_ids, frames_pitch, lens, cfg, self.pitch_layers)
         return total, LossTerms(terms)

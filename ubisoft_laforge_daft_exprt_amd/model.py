@@ -367,6 +367,7 @@ class DaftExprt(nn.Module):
         # execution state of THIS model (operand precision, pack epoch, gradient sink): shared by all of its sub-modules, read
         # by nobody else.  It starts from the package default (``set_precision``) and is switched with ``model.set_precision``.
         self.runtime = ops.Runtime(ops.DEFAULT.precision)
+        self.backward_split = None                 # a list while a trainer wants the backward cut at the accent embedding
         for m in self.modules():
             m._dx_rt = self.runtime
 
@@ -430,6 +431,12 @@ class DaftExprt(nn.Module):
             accent_emb = external_accent_emb
         else:
             accent_emb = self.accent_encoder(frames_energy, frames_pitch, mel_specs, out_lens)
+            if self.backward_split is not None:
+                # two-phase backward (trainer.Trainer): everything downstream of the accent embedding first -- its gradient buckets
+                # can then be exchanged while the accent encoder's backward (the largest module) still runs
+                leaf = accent_emb.detach().requires_grad_(True)
+                self.backward_split.append((accent_emb, leaf))
+                accent_emb = leaf
         speaker_preds = self.speaker_classifier(accent_emb)
         film = self.style_adapter(accent_emb + spk_emb)
         enc_outputs = self.phoneme_encoder(symbols, film['phoneme_encoder'], in_lens)

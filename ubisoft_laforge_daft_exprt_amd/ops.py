@@ -27,6 +27,7 @@ class Runtime:
         self.pack_epoch = 0          # "an optimiser wrote the parameters through raw pointers" (optim.FusedAdam)
         self.sink = False            # backward kernels accumulate straight into pre-zeroed ``param.grad`` (ddp.GradientReducer)
         self.launch_log = None       # bench.py: (kind, ...) records of every launch, to price algorithmic FLOPs / bytes
+        self.seed_offset = None      # device int64 scalar added to every dropout seed on the device (graph replays bump it)
         self._packs = []             # weak refs to this runtime's PackedWeight objects (one-launch batched re-pack)
         self._tables = {}
 
@@ -203,7 +204,7 @@ class PackedWeight:
         prec = prec or self.rt.precision
         img = self._image(prec)
         key = self._current_key()
-        if key != img.key:
+        if key != img.key:                     # (the padded speaker-logit layer's copy bumps its _version under capture: recorded too)
             lib().dx_pack_weights(_p(self.weight.detach()), _p(img.fwd), _p(img.bwd), self.cout, self.cin, self.taps, img.half, _stream())
             img.key = key
         return img
@@ -329,23 +330,24 @@ def colsum(x, C=None):
     return out
 
 
-def attention_fwd(qkv, lens, heads, seed, p_drop, prec=None):
+def attention_fwd(qkv, lens, heads, seed, p_drop, prec=None, seed_offset=None):
     B, N, D3 = qkv.shape
     D = D3 // 3
     ctx = torch.empty(B, N, D, dtype=torch.float32, device=qkv.device)
     lse = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device)
-    lib().dx_attention_fwd(_p(qkv), _rows(qkv), _p(lens), _p(ctx), D, _p(lse), B, N, heads, D, seed, float(p_drop), _half(prec or DEFAULT.precision),
-                           _is_bf16(qkv), _stream())
+    lib().dx_attention_fwd(_p(qkv), _rows(qkv), _p(lens), _p(ctx), D, _p(lse), B, N, heads, D, seed, _p(seed_offset), float(p_drop),
+                           _half(prec or DEFAULT.precision), _is_bf16(qkv), _stream())
     return ctx, lse
 
 
-def attention_bwd(qkv, ctx, dctx, lse, lens, heads, seed, p_drop, out_dtype=torch.float32, prec=None):
+def attention_bwd(qkv, ctx, dctx, lse, lens, heads, seed, p_drop, out_dtype=torch.float32, prec=None, seed_offset=None):
     B, N, D3 = qkv.shape
     D = D3 // 3
     dqkv = torch.empty(B, N, D3, dtype=out_dtype, device=qkv.device)
     delta = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device)
     lib().dx_attention_bwd(_p(qkv), _rows(qkv), _p(ctx), _p(dctx), _rows(dctx), _p(lse), _p(delta), _p(lens), _p(dqkv), _rows(dqkv),
-                           B, N, heads, D, seed, float(p_drop), _half(prec or DEFAULT.precision), _is_bf16(qkv), _is_bf16(dqkv), _stream())
+                           B, N, heads, D, seed, _p(seed_offset), float(p_drop), _half(prec or DEFAULT.precision), _is_bf16(qkv), _is_bf16(dqkv),
+                           _stream())
     return dqkv
 
 
@@ -354,7 +356,7 @@ def gemm_shadow(prec=None):
     return bool(_half(prec or DEFAULT.precision))
 
 
-def ln_fwd(a, res, w, b, film, lens, *, seed_pre=0, p_pre=0.0, seed_post=0, p_post=0.0, halo=0, shadow=False):
+def ln_fwd(a, res, w, b, film, lens, *, seed_pre=0, p_pre=0.0, seed_post=0, p_post=0.0, halo=0, shadow=False, seed_offset=None):
     """In place on ``a`` (becomes z = drop(a) + res).  Returns (y, mean, rstd) or, with ``shadow``, (y, mean, rstd, y_bf16)."""
     B, N, C = a.shape
     y = torch.empty_like(a)
@@ -362,12 +364,12 @@ def ln_fwd(a, res, w, b, film, lens, *, seed_pre=0, p_pre=0.0, seed_post=0, p_po
     mean = torch.empty(B, N, dtype=torch.float32, device=a.device)
     rstd = torch.empty(B, N, dtype=torch.float32, device=a.device)
     lib().dx_ln_fwd(_p(a), _p(res), _p(w), _p(b), _p(film), 0 if film is None else film.stride(0), _p(lens), int(halo), _p(y), _p(mean), _p(rstd),
-                    B, N, C, seed_pre, float(p_pre), seed_post, float(p_post), _is_bf16(a), _p(y_h), _stream())
+                    B, N, C, seed_pre, float(p_pre), seed_post, float(p_post), _p(seed_offset), _is_bf16(a), _p(y_h), _stream())
     return (y, mean, rstd, y_h) if shadow else (y, mean, rstd)
 
 
 def ln_bwd(dy, z, mean, rstd, w, b, film, lens, *, relu_mask=False, want_da=False, seed_pre=0, p_pre=0.0, seed_post=0, p_post=0.0,
-           arena=None, w_sink=None, b_sink=None, halo=0, shadow=False):
+           arena=None, w_sink=None, b_sink=None, halo=0, shadow=False, seed_offset=None):
     """Returns (dz, da or None, dw, db, dfilm or None[, dg_bf16]); dw/db are None when accumulated straight into the given sinks."""
     B, N, C = z.shape
     dz = torch.empty_like(z)
@@ -378,7 +380,7 @@ def ln_bwd(dy, z, mean, rstd, w, b, film, lens, *, relu_mask=False, want_da=Fals
     dfilm = _zeros(arena, B, 2 * C, device=z.device) if film is not None else None
     lib().dx_ln_bwd(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(film), 0 if film is None else film.stride(0), _p(lens), int(halo),
                     _p(dz), _p(da), _p(dw), _p(db), _p(dfilm), 2 * C, B, N, C, int(relu_mask),
-                    seed_pre, float(p_pre), seed_post, float(p_post), _is_bf16(z), _p(dg_h), _stream())
+                    seed_pre, float(p_pre), seed_post, float(p_post), _p(seed_offset), _is_bf16(z), _p(dg_h), _stream())
     out = (dz, da, (None if w_sink is not None else dw), (None if b_sink is not None else db), dfilm)
     return out + (dg_h,) if shadow else out
 

@@ -10,6 +10,18 @@ One ``Trainer.train_step`` = src/daft_exprt/train.py:390-539 without logging / v
     clip_grad_norm_(parameters, grad_clip_thresh) + Adam(lr(iteration)) as ONE fused launch per bucket  train.py:443-445
     iteration += 1; lr = update_learning_rate(hparams, iteration)                                        train.py:517-539
 
+MI355X-specific structure of one update (``use_graphs=True``, the default):
+  * the device work of a step is TWO captured HIP graphs per padded batch shape, replayed with the new batch copied into their
+    static input buffers: graph A = zero the gradient buckets, forward, loss, backward of everything downstream of the accent
+    embedding; graph B = backward of the accent encoder (~45 % of the backward).  ~600 kernel launches cost the host 7 ms per
+    step when issued one by one from Python -- as much as the GPU needs to execute them -- and ~20 us as two graph launches.
+  * the cut is also where the gradient exchange overlaps: the buckets of graph A's parameters are all-reduced (RCCL, its own
+    stream) while graph B runs; only the accent encoder's buckets are exchanged after it.  The same two-phase order runs eagerly
+    (``use_graphs=False``), and on one GPU.
+  * what changes between replays lives in device memory the graphs read: the batch, the lengths, the adversarial-loss weight, and
+    a dropout seed offset that graph A increments (``runtime.seed_offset``), so every replay draws fresh dropout masks.
+  * the optimiser (fused Adam, LR by value) and the one-launch weight re-pack stay outside the graphs: ten launches.
+
 Like the reference, a NaN loss does not stop the update (train.py:445-450 only skips LOGGING); ``nan_steps`` counts them.
 The iteration counter starts at 1 (train.py:286) and the learning rate of step ``i`` is ``update_learning_rate(hparams, i)``.
 ``save_checkpoint`` / ``load_checkpoint`` use the reference's dict layout (train.py:63-145) including the torch.optim.Adam
@@ -25,11 +37,27 @@ from .ddp import GradientReducer
 from .optim import FusedAdam, update_learning_rate
 
 
+def _group_of(name: str) -> int:
+    """gradient-exchange groups = the two backward phases: 1 = accent encoder (phase B), 0 = everything else (phase A)"""
+    return 1 if name.startswith('accent_encoder.') else 0
+
+
+class _StepGraphs:
+    """The two captured graphs of one padded batch shape with their static inputs and outputs."""
+    __slots__ = ('graph_a', 'graph_b', 'inputs', 'loss', 'terms_dev', 'hits')
+
+
 class Trainer:
-    def __init__(self, model, criterion, hparams, conditioner=None, process_group=None, bucket_mb=16.0, grad_sink=True):
+    def __init__(self, model, criterion, hparams, conditioner=None, process_group=None, bucket_mb=16.0, grad_sink=True,
+                 use_graphs=True, max_graphs=16):
         self.model, self.criterion, self.hparams, self.conditioner = model, criterion, hparams, conditioner
         self.device = next(model.parameters()).device
-        self.reducer = GradientReducer(model, bucket_mb=bucket_mb, process_group=process_group, grad_sink=grad_sink)
+        self.reducer = GradientReducer(model, bucket_mb=bucket_mb, process_group=process_group, grad_sink=grad_sink, group_of=_group_of)
+        self.use_graphs, self.max_graphs = bool(use_graphs), int(max_graphs)
+        self.graphs = {}
+        self.adv_weight = torch.zeros((), dtype=torch.float32, device=self.device)    # read by the captured loss
+        if model.runtime.seed_offset is None:
+            model.runtime.seed_offset = torch.zeros((), dtype=torch.int64, device=self.device)
         self.optimizer = FusedAdam(self.reducer, lr=hparams.initial_learning_rate, betas=hparams.betas, eps=hparams.epsilon,
                                    weight_decay=hparams.weight_decay, grad_clip_thresh=hparams.grad_clip_thresh)
         self.accumulation_steps = int(getattr(hparams, 'accumulation_steps', 1))
@@ -39,32 +67,105 @@ class Trainer:
         self.best_val_loss = float('inf')
         model.train()
 
-    def _micro_batch(self, batch):
-        """train.py:395-422: parse, condition, forward, loss."""
-        inputs, targets = self.model.parse_batch(self.device, batch)
+    # -- device work of one update ----------------------------------------------------------------------------------------
+    def _forward_loss(self, inputs, targets, iteration):
+        """train.py:405-422 on parsed device tensors: RAW frame prosody for the consistency losses, conditioning, forward, loss."""
         raw_frames_energy, raw_frames_pitch = inputs[6], inputs[7]       # the frozen pitch predictor outputs RAW pitch
         if self.conditioner is not None:
             inputs = self.conditioner.process_batch(inputs, self.device)   # length tensors pass through (host lengths ride along)
         targets = (targets[0], inputs[3], inputs[4], targets[3], targets[4], targets[5], raw_frames_energy, raw_frames_pitch)
         outputs = self.model(inputs)
-        return self.criterion(outputs, targets, self.iteration)
+        return self.criterion(outputs, targets, iteration)
 
-    def train_step(self, batches):
-        """``batches``: the ``accumulation_steps`` micro-batches (reference 14-tuples) of one parameter update.
-        Returns (summed loss tensor / accumulation_steps, list of per-micro-batch LossTerms, gradient norm tensor)."""
-        batches = list(batches)
-        if len(batches) != self.accumulation_steps:
-            raise ValueError(f'expected {self.accumulation_steps} micro-batches, got {len(batches)}')
-        self.reducer.zero_grad()
+    def _phases(self, parsed, iteration, launch):
+        """zero the buckets; per micro-batch: forward, loss, backward phase A (everything downstream of the accent embedding), then
+        phase B (the accent encoder).  ``launch(gid)`` is called when group ``gid``'s gradients are complete.
+        Returns (loss summed over micro-batches, list of LossTerms, callable running phase B)."""
+        model, red, k = self.model, self.reducer, self.accumulation_steps
+        red.zero_grad()
+        model.backward_split = []
         tot, terms = None, []
-        for k, batch in enumerate(batches):
-            loss, indiv = self._micro_batch(batch)
-            loss = loss / self.accumulation_steps
-            with self.reducer.accumulate(sync=(k == len(batches) - 1)):
+        for inputs, targets in parsed:
+            loss, indiv = self._forward_loss(inputs, targets, iteration)
+            loss = loss / k
+            with red.accumulate(sync=False):                 # the exchange is launched explicitly, group by group
                 loss.backward()
             tot = loss.detach() if tot is None else tot + loss.detach()
             terms.append(indiv)
-        self.reducer.finish()
+        cuts, model.backward_split = model.backward_split, None
+        launch(0)
+
+        def phase_b():
+            for emb, leaf in cuts:
+                with red.accumulate(sync=False):
+                    emb.backward(leaf.grad)
+            launch(1)
+        return tot, terms, phase_b
+
+    def _parse(self, batches):
+        parsed = [self.model.parse_batch(self.device, b) for b in batches]
+        key = tuple((tuple(i[0].shape), tuple(i[8].shape)) for i, _ in parsed)     # (B, L_max), (B, n_mel, T_max) per micro-batch
+        return parsed, key
+
+    def _capture(self, parsed, key):
+        """Two graphs for this padded shape.  One eager step on a side stream first (kernel attributes, weight packs, allocator),
+        with the optimiser NOT applied: the captured step then sees the same state a replay will."""
+        g = _StepGraphs()
+        static = []
+        for inputs, targets in parsed:
+            si = tuple(t.clone() for t in inputs)
+            for i in (5, 9):                                  # host lengths ride along: shapes / maxima are part of the key
+                h = getattr(inputs[i], '_dx_host_lengths', None)
+                si[i]._dx_host_lengths = h if h is not None else inputs[i].tolist()   # (a sync, at capture time only)
+            st = (si[1], si[3], si[4], si[8], si[9], si[10])  # the targets alias the inputs, as parse_batch builds them
+            static.append((si, st))
+        rt = self.model.runtime
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            _, _, pb = self._phases(static, self.adv_weight, lambda gid: None)
+            pb()
+        torch.cuda.current_stream().wait_stream(side)
+        g.graph_a, g.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g.graph_a):
+            rt.seed_offset.add_(1)                            # a new dropout stream per replay (the seeds in the launches are frozen)
+            g.loss, terms, phase_b = self._phases(static, self.adv_weight, lambda gid: None)
+        g.terms_dev = [t._device_terms for t in terms]        # static device tensors: wrapped anew after every replay
+        with torch.cuda.graph(g.graph_b, pool=g.graph_a.pool()):
+            phase_b()
+        g.inputs, g.hits = static, 0
+        if len(self.graphs) >= self.max_graphs:               # evict the least used shape (its pool is freed with it)
+            del self.graphs[min(self.graphs, key=lambda q: self.graphs[q].hits)]
+        self.graphs[key] = g
+        return g
+
+    def train_step(self, batches):
+        """``batches``: the ``accumulation_steps`` micro-batches (reference 14-tuples) of one parameter update.
+        Returns (loss tensor = mean over micro-batches, list of per-micro-batch LossTerms, gradient norm tensor)."""
+        batches = list(batches)
+        if len(batches) != self.accumulation_steps:
+            raise ValueError(f'expected {self.accumulation_steps} micro-batches, got {len(batches)}')
+        parsed, key = self._parse(batches)
+        red = self.reducer
+        if self.use_graphs:
+            self.adv_weight.fill_(self.criterion.update_adversarial_weight(self.iteration))
+            g = self.graphs.get(key)
+            if g is None:
+                g = self._capture(parsed, key)
+            g.hits += 1
+            for (si, _), (inputs, _) in zip(g.inputs, parsed):
+                for dst, src in zip(si, inputs):
+                    dst.copy_(src, non_blocking=True)
+            g.graph_a.replay()
+            red.launch_group(0)                               # exchanged while graph B (accent-encoder backward) runs
+            g.graph_b.replay()
+            red.launch_group(1)
+            from .loss import LossTerms
+            tot, terms = g.loss, [LossTerms(t) for t in g.terms_dev]
+        else:
+            tot, terms, phase_b = self._phases(parsed, self.iteration, red.launch_group)
+            phase_b()
+        red.finish()
         grad_norm = self.optimizer.step(lr=self.learning_rate)
         self.iteration += 1
         self.learning_rate = update_learning_rate(self.hparams, self.iteration)
