@@ -138,8 +138,16 @@ int dx_upsample_sym_bwd(const float* dxs_in, const float* dsigma, const float* x
 int dx_mel_stats(const float* mel_pred, const float* mel_target, float* ep, float* et, float* l1sum, float* l2sum,
                  int B, int M, int T, void* stream);
 int dx_energy_diff(const float* ep, const float* et, const int* lens, float* des, float* esum, int B, int T, void* stream);
+/* e_per_total = 1: c_e is divided by sum_b lens[b] on the device (loss.py:129 normalises the energy term by the batch's valid frames) */
 int dx_mel_grad(const float* mel_pred, const float* mel_target, const float* ep, const float* des, const int* lens,
-                float c_l1, float c_l2, float c_e, float* dmel, int B, int M, int T, void* stream);
+                float c_l1, float c_l2, float c_e, int e_per_total, float* dmel, int B, int M, int T, void* stream);
+/* loss.py:85-157 assembled on the device: terms[7] = {speaker_loss, speaker_ce_raw, post_mult_loss, mel_l1, mel_l2, energy, pitch},
+ * total[1] = speaker + post_mult + l1 + l2 + ecw * energy + pcw * pitch; d_spk = dlogits * w; d_pm = pmw * pm / ||pm||_2.
+ * w = *spk_w_dev if given (device scalar, re-read by every replay of a captured graph) else spk_w.  NULL ce / pm / esum / psum: term off. */
+int dx_loss_finalize(const float* ce, const float* spk_w_dev, float spk_w, const float* dlogits, float* d_spk, int n_logits,
+                     const float* pm, float* d_pm, int n_pm, float pmw,
+                     const float* l1sum, const float* l2sum, const int* lens, int B, int M, float msw,
+                     const float* esum, float ecw, const float* psum, float pcw, float* terms, float* total, void* stream);
 int dx_pitch_mse(const float* pp, const float* gt, const int* lens, float* sums, int B, int T, void* stream);
 int dx_pitch_grad(const float* pp, const float* gt, const int* lens, const float* sums, float scale, float* dpp, int B, int T, void* stream);
 

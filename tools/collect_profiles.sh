@@ -20,7 +20,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- p
 echo "write done"
 cd $ROOT
 python3 tools/summarize_profile.py pmc $OUT/fetch $OUT/write $PREC $OUT/${TAG}_pmc_traffic.json > $OUT/pmc_summary.log 2>&1 || { tail -5 $OUT/pmc_summary.log; exit 1; }
-python3 tools/summarize_profile.py stats $OUT/trace 7 $OUT/${TAG}_${PREC}_kernel_stats.csv $OUT/${TAG}_${PREC}_kernel_table.json $OUT/${TAG}_pmc_traffic.json || exit 1
+python3 tools/summarize_profile.py stats $OUT/trace 8 $OUT/${TAG}_${PREC}_kernel_stats.csv $OUT/${TAG}_${PREC}_kernel_table.json $OUT/${TAG}_pmc_traffic.json || exit 1
 # the raw traces are large: keep only the summaries
 rm -rf $OUT/trace $OUT/fetch $OUT/write
 ls -la $OUT

@@ -73,8 +73,14 @@ __global__ __launch_bounds__(256) void energy_diff_kernel(const float* __restric
 // dmel[b,m,t] = c_l1/len_b * sign(d) + c_l2/len_b * 2 d + c_e * (sum_{|k|<=2} des[t+k] / 5) * exp(p)^2 / ep[t]
 __global__ __launch_bounds__(256) void mel_grad_kernel(const float* __restrict__ mp, const float* __restrict__ mt,
                                                        const float* __restrict__ ep, const float* __restrict__ des, const int* __restrict__ lens,
-                                                       float c_l1, float c_l2, float c_e, float* __restrict__ dmel, int M, int T) {
+                                                       float c_l1, float c_l2, float c_e, int e_per_total, float* __restrict__ dmel, int M, int T) {
   const int b = blockIdx.y, mg = threadIdx.x / MEL_TT, t = blockIdx.x * MEL_TT + (threadIdx.x & (MEL_TT - 1));
+  if (e_per_total) {                                    // energy term normalised by the batch's total valid length (loss.py:129):
+    __shared__ float scratch[4];                        // summed here, on the device, so that no host value is frozen into a graph
+    float n = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.y; i += 256) n += (float)lens[i];
+    c_e /= block_sum_256(n, scratch);
+  }
   if (t >= T) return;
   const float inv_len = 1.f / (float)lens[b];
   float ge = 0.f;
@@ -124,6 +130,42 @@ __global__ __launch_bounds__(256) void pitch_grad_kernel(const float* __restrict
   dpp[(size_t)b * T + t] = v;
 }
 
+// The seven loss terms and the total (loss.py:85-157) from the reductions above, plus the two small gradients, in one block:
+// replaces ~30 one-element ATen launches per step.
+struct LossFinalizeArgs {
+  const float* ce; const float* spk_w_dev; float spk_w;
+  const float* dlogits; float* d_spk; int n_logits;
+  const float* pm; float* d_pm; int n_pm; float pmw;
+  const float* l1sum; const float* l2sum; const int* lens; int B; int M; float msw;
+  const float* esum; float ecw; const float* psum; float pcw;
+  float* terms; float* total;
+};
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const LossFinalizeArgs a) {
+  __shared__ float scratch[4];
+  const int tid = threadIdx.x;
+  const float w = a.spk_w_dev ? *a.spk_w_dev : a.spk_w;
+  for (int i = tid; i < a.n_logits; i += 256) a.d_spk[i] = a.dlogits[i] * w;
+  float sq = 0.f;
+  for (int i = tid; i < a.n_pm; i += 256) sq += a.pm[i] * a.pm[i];
+  const float nrm = sqrtf(block_sum_256(sq, scratch));
+  for (int i = tid; i < a.n_pm; i += 256) a.d_pm[i] = a.pmw * a.pm[i] / nrm;
+  float l1 = 0.f, l2 = 0.f, n = 0.f;
+  for (int i = tid; i < a.B; i += 256) {
+    const float len = (float)a.lens[i], d = (float)a.M * len;
+    l1 += a.l1sum[i] / d; l2 += a.l2sum[i] / d; n += len;
+  }
+  l1 = block_sum_256(l1, scratch);
+  l2 = block_sum_256(l2, scratch);
+  n = block_sum_256(n, scratch);
+  if (tid == 0) {
+    const float ce = a.ce ? *a.ce : 0.f;
+    const float t0 = w * ce, t2 = a.n_pm ? a.pmw * nrm : 0.f, t3 = a.msw * l1 / (float)a.B, t4 = a.msw * l2 / (float)a.B;
+    const float t5 = a.esum ? *a.esum / n : 0.f, t6 = a.psum ? a.psum[0] / (a.psum[1] + 1e-5f) : 0.f;
+    a.terms[0] = t0; a.terms[1] = ce; a.terms[2] = t2; a.terms[3] = t3; a.terms[4] = t4; a.terms[5] = t5; a.terms[6] = t6;
+    *a.total = t0 + t2 + t3 + t4 + a.ecw * t5 + a.pcw * t6;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -145,11 +187,27 @@ int dx_energy_diff(const float* ep, const float* et, const int* lens, float* des
 }
 
 int dx_mel_grad(const float* mel_pred, const float* mel_target, const float* ep, const float* des, const int* lens,
-                float c_l1, float c_l2, float c_e, float* dmel, int B, int M, int T, void* stream) {
+                float c_l1, float c_l2, float c_e, int e_per_total, float* dmel, int B, int M, int T, void* stream) {
   DX_REQUIRE(mel_pred && mel_target && lens && dmel && B > 0 && M > 0 && T > 0, "dx_mel_grad: bad arguments");
   DX_REQUIRE(c_e == 0.f || (ep && des), "dx_mel_grad: energy term needs ep and des");
-  hipLaunchKernelGGL(mel_grad_kernel, dim3(dx_cdiv(T, MEL_TT), B), dim3(256), 0, (hipStream_t)stream, mel_pred, mel_target, ep, des, lens, c_l1, c_l2, c_e, dmel, M, T);
+  hipLaunchKernelGGL(mel_grad_kernel, dim3(dx_cdiv(T, MEL_TT), B), dim3(256), 0, (hipStream_t)stream, mel_pred, mel_target, ep, des, lens, c_l1, c_l2, c_e, e_per_total, dmel, M, T);
   DX_LAUNCH_CHECK("dx_mel_grad");
+  return DX_OK;
+}
+
+// terms[7] = {speaker_loss, speaker_ce_raw, post_mult_loss, mel_l1, mel_l2, energy_consistency, pitch_consistency}, total[1] =
+// their weighted sum; d_spk = dlogits * w, d_pm = pmw * pm / ||pm||.  w = *spk_w_dev when given (a device scalar a captured graph
+// re-reads on every replay), else spk_w.  NULL ce / pm / esum / psum switch the corresponding term off.
+int dx_loss_finalize(const float* ce, const float* spk_w_dev, float spk_w, const float* dlogits, float* d_spk, int n_logits,
+                     const float* pm, float* d_pm, int n_pm, float pmw,
+                     const float* l1sum, const float* l2sum, const int* lens, int B, int M, float msw,
+                     const float* esum, float ecw, const float* psum, float pcw, float* terms, float* total, void* stream) {
+  DX_REQUIRE(l1sum && l2sum && lens && terms && total && B > 0 && M > 0, "dx_loss_finalize: bad arguments");
+  DX_REQUIRE(n_logits == 0 || (dlogits && d_spk && ce), "dx_loss_finalize: speaker term needs ce, dlogits, d_spk");
+  DX_REQUIRE(n_pm == 0 || (pm && d_pm), "dx_loss_finalize: post-multiplier term needs pm, d_pm");
+  LossFinalizeArgs a{ce, spk_w_dev, spk_w, dlogits, d_spk, n_logits, pm, d_pm, n_pm, pmw, l1sum, l2sum, lens, B, M, msw, esum, ecw, psum, pcw, terms, total};
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+  DX_LAUNCH_CHECK("dx_loss_finalize");
   return DX_OK;
 }
 

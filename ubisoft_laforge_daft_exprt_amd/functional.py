@@ -129,7 +129,7 @@ class PaddedLinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        dyp = torch.zeros(dy.shape[0], ctx.pack.cout, dtype=dy.dtype, device=dy.device)
+        dyp = ops._zeros(ctx.pack.rt.arena, dy.shape[0], ctx.pack.cout, device=dy.device)
         dyp[:, :ctx.cout].copy_(dy)
         dw, db = ops.conv_wgrad(dyp, x, ctx.pack, prec=ctx.prec)
         dw, db = dw[:ctx.cout], db[:ctx.cout]
@@ -184,7 +184,8 @@ class FFTBlockFn(torch.autograd.Function):
         B, _, D = x.shape
         Fc = h.shape[2]
         pad = ops.ZeroArena.padded
-        arena = ops.ZeroArena(x.device, 6 * pad(D) + pad(B * 2 * D) + 2 * pad(3 * D * Fc) + pad(Fc) + pad(D * D) + pad(3 * D * D) + pad(3 * D) + 64)
+        # the step's arena (trainer) or, outside a trainer step, one fill for this block's accumulators
+        arena = packs['in'].rt.arena or ops.ZeroArena(x.device, 6 * pad(D) + pad(B * 2 * D) + 2 * pad(3 * D * Fc) + pad(Fc) + pad(D * D) + pad(3 * D * D) + pad(3 * D) + 64)
         P = packs.get('params', {})
         prec = ctx.prec
         sk = {k: _sink(v, ctx.sink) for k, v in P.items()}
@@ -249,6 +250,7 @@ class AccentFrontFn(torch.autograd.Function):
         x0, h0, m0, r0, y0, h1, m1, r1, y1, h2, m2, r2, energy, pitch, l0_w, l0_b, l1_w, l1_b, l2_w, l2_b = ctx.saved_tensors
         lens, packs, p, seeds = ctx.lens, ctx.packs, ctx.p, ctx.seeds
         so = ctx.seed_offset
+        arena = packs['p0'].rt.arena
         dout = ops.mask_rows(dout.contiguous(), lens.i32)
         dwe, dbe, dwp, dbp = ops.scalar_conv_wgrad(dout, energy, pitch, lens.i32, sinks=tuple(_sink(q, ctx.sink) for q in ctx.emb_params))
         L = lens.i32
@@ -257,16 +259,16 @@ class AccentFrontFn(torch.autograd.Function):
         sk = {k: _sink(v, ctx.sink) for k, v in P.items()}
         g = sk.get
         dz2, _, dl2_w, dl2_b, _ = ops.ln_bwd(dout, h2, m2, r2, l2_w, l2_b, None, L, relu_mask=True, seed_post=seeds[2], p_post=p, seed_offset=so,
-                                              w_sink=g('l2_w'), b_sink=g('l2_b'), halo=0)
-        dc2_w, dc2_b = ops.conv_wgrad(dz2, y1, packs['p2'], L, 0, w_sink=g('c2_w'), b_sink=g('c2_b'), prec=prec)
+                                              w_sink=g('l2_w'), b_sink=g('l2_b'), halo=0, arena=arena)
+        dc2_w, dc2_b = ops.conv_wgrad(dz2, y1, packs['p2'], L, 0, w_sink=g('c2_w'), b_sink=g('c2_b'), prec=prec, arena=arena)
         dy1 = ops.conv_gemm(dz2, packs['p2'], None, transpose=True, lens=L, halo=1, out_dtype=h1.dtype, prec=prec)
         dz1, _, dl1_w, dl1_b, _ = ops.ln_bwd(dy1, h1, m1, r1, l1_w, l1_b, None, L, relu_mask=True, seed_post=seeds[1], p_post=p, seed_offset=so,
-                                              w_sink=g('l1_w'), b_sink=g('l1_b'), halo=1)
-        dc1_w, dc1_b = ops.conv_wgrad(dz1, y0, packs['p1'], L, 1, w_sink=g('c1_w'), b_sink=g('c1_b'), prec=prec)
+                                              w_sink=g('l1_w'), b_sink=g('l1_b'), halo=1, arena=arena)
+        dc1_w, dc1_b = ops.conv_wgrad(dz1, y0, packs['p1'], L, 1, w_sink=g('c1_w'), b_sink=g('c1_b'), prec=prec, arena=arena)
         dy0 = ops.conv_gemm(dz1, packs['p1'], None, transpose=True, lens=L, halo=2, out_dtype=h0.dtype, prec=prec)
         dz0, _, dl0_w, dl0_b, _ = ops.ln_bwd(dy0, h0, m0, r0, l0_w, l0_b, None, L, relu_mask=True, seed_post=seeds[0], p_post=p, seed_offset=so,
-                                              w_sink=g('l0_w'), b_sink=g('l0_b'), halo=2)
-        dc0_w, dc0_b = ops.conv_wgrad(dz0, x0, packs['p0'], L, 2, w_sink=g('c0_w'), b_sink=g('c0_b'), prec=prec)
+                                              w_sink=g('l0_w'), b_sink=g('l0_b'), halo=2, arena=arena)
+        dc0_w, dc0_b = ops.conv_wgrad(dz0, x0, packs['p0'], L, 2, w_sink=g('c0_w'), b_sink=g('c0_b'), prec=prec, arena=arena)
         return (None, None, None, None, None, None, None, None,
                 dc0_w, dc0_b, dl0_w, dl0_b, dc1_w, dc1_b, dl1_w, dl1_b, dc2_w, dc2_b, dl2_w, dl2_b, dwe, dbe, dwp, dbp)
 
@@ -293,29 +295,30 @@ class MeanPoolFn(torch.autograd.Function):
     """sum over time / length (model.py:714)."""
 
     @staticmethod
-    def forward(ctx, x, lens):
+    def forward(ctx, x, lens, rt=None):
         ctx.lens, ctx.N = lens, x.shape[1]
-        return ops.mean_pool(x, lens.i32)
+        return ops.mean_pool(x, lens.i32, arena=None if rt is None else rt.arena)
 
     @staticmethod
     def backward(ctx, dout):
-        return ops.mean_pool_bwd(dout.contiguous(), ctx.lens.i32, ctx.N), None
+        return ops.mean_pool_bwd(dout.contiguous(), ctx.lens.i32, ctx.N), None, None
 
 
 class EmbedPosFn(torch.autograd.Function):
     """mask(embedding[symbols] + position) (model.py:597-604)."""
 
     @staticmethod
-    def forward(ctx, symbols, emb, pe, lens):
+    def forward(ctx, symbols, emb, pe, lens, rt=None):
         symbols = symbols.contiguous()
         ctx.save_for_backward(symbols)
-        ctx.lens, ctx.rows = lens, emb.shape[0]
+        ctx.lens, ctx.rows, ctx.rt = lens, emb.shape[0], rt
         return ops.add_pos(None, symbols, emb, pe, lens.i32)
 
     @staticmethod
     def backward(ctx, dout):
         (symbols,) = ctx.saved_tensors
-        return None, ops.embedding_bwd(dout.contiguous(), symbols, ctx.lens.i32, ctx.rows), None, None
+        arena = None if ctx.rt is None else ctx.rt.arena
+        return None, ops.embedding_bwd(dout.contiguous(), symbols, ctx.lens.i32, ctx.rows, arena=arena), None, None, None
 
 
 class AddPosFn(torch.autograd.Function):
@@ -345,6 +348,7 @@ class GaussianUpsampleFn(torch.autograd.Function):
         ctx.lens = lens
         ctx.params = (wd, bd, we, be, wp, bp, wr, br)
         ctx.sink = bool(rt is not None and rt.sink)
+        ctx.rt = rt
         ctx.mark_non_differentiable(weights)
         return xup, weights
 
@@ -352,7 +356,7 @@ class GaussianUpsampleFn(torch.autograd.Function):
     def backward(ctx, dxup, _dweights):
         xs, z, sigma, mu, weights, dur_float, energy, pitch, wd, bd, wr = ctx.saved_tensors
         lens = ctx.lens
-        dxs, dsigma = ops.upsample_bwd(dxup.contiguous(), xs, mu, sigma, weights, lens.i32)
+        dxs, dsigma = ops.upsample_bwd(dxup.contiguous(), xs, mu, sigma, weights, lens.i32, arena=None if ctx.rt is None else ctx.rt.arena)
         pwd, pbd, pwe, pbe, pwp, pbp, pwr, pbr = ctx.params
         sk = lambda q: _sink(q, ctx.sink)
         swr = sk(pwr)

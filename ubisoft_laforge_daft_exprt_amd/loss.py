@@ -71,34 +71,23 @@ class _LossFn(torch.autograd.Function):
     """total = w_spk * CE + pmw * ||pm||_2 + msw * (L1 + L2) + ecw * E + pcw * P; gradients computed in the forward."""
 
     @staticmethod
-    def forward(ctx, mel_pred, speaker_preds, post_multipliers, mel_target, speaker_ids, frames_pitch, lens: Lengths, cfg, pitch_layers):
+    def forward(ctx, mel_pred, speaker_preds, post_multipliers, mel_target, speaker_ids, frames_pitch, lens: Lengths, cfg, pitch_layers, rt=None):
         dev = mel_pred.device
         B, M, T = mel_pred.shape
         mel_pred, mel_target = mel_pred.contiguous(), mel_target.contiguous()
-        terms = torch.zeros(7, dtype=torch.float32, device=dev)   # speaker_loss, ce_raw, post_mult, l1, l2, energy, pitch
-        d_spk = d_pm = None
+        arena = None if rt is None else rt.arena
+        ce = dlogits = None
         if speaker_preds is not None:
             ce, dlogits = ops.cross_entropy(speaker_preds.contiguous(), speaker_ids.contiguous())
-            terms[1:2] = ce
-            terms[0:1] = cfg['spk_weight'] * ce               # python float, or a device scalar (captured graphs: updated per replay)
-            d_spk = dlogits * cfg['spk_weight']
-        if post_multipliers is not None:
-            nrm = torch.linalg.vector_norm(post_multipliers.detach())      # 16 numbers
-            terms[2:3] = cfg['pmw'] * nrm
-            d_pm = cfg['pmw'] * post_multipliers.detach() / nrm
-        ep, et, sums = ops.mel_stats(mel_pred, mel_target)
-        denom = float(M) * lens.i32.float()
-        terms[3:4] = cfg['msw'] * (sums[0] / denom).mean()
-        terms[4:5] = cfg['msw'] * (sums[1] / denom).mean()
-        des, c_e = None, 0.0
+        pm = post_multipliers.detach().contiguous() if post_multipliers is not None else None      # 16 numbers
+        ep, et, sums = ops.mel_stats(mel_pred, mel_target, arena=arena)
+        des = esum = None
         if cfg['ecw'] > 0:
-            des, esum = ops.energy_diff(ep, et, lens.i32)
-            # 1 / sum of lengths as a DEVICE value: a host float here would be frozen into a captured graph
-            inv_total = 1.0 / lens.i32.sum().to(torch.float32)
-            terms[5:6] = esum * inv_total
-            des = des * inv_total
-            c_e = cfg['ecw']
-        dmel = ops.mel_grad(mel_pred, mel_target, ep, des, lens.i32, cfg['msw'] / (M * B), cfg['msw'] / (M * B), c_e)
+            des, esum = ops.energy_diff(ep, et, lens.i32, arena=arena)
+        # energy term: ecw / (sum of valid lengths), the division done on the device (nothing host-side is frozen into a graph)
+        dmel = ops.mel_grad(mel_pred, mel_target, ep, des, lens.i32, cfg['msw'] / (M * B), cfg['msw'] / (M * B), cfg['ecw'] if des is not None else 0.0,
+                            e_per_total=True)
+        psum = None
         if pitch_layers is not None and frames_pitch is not None and cfg['pcw'] > 0:
             # frozen predictor on the predicted mel, channels-last; gradient flows through it to the mel only
             x = ops.transpose(mel_pred)                                          # (B, T, M)
@@ -112,10 +101,9 @@ class _LossFn(torch.autograd.Function):
             last = pitch_layers[-1]
             pp = ops.conv_gemm(x, last['pack'], last['b'], lens=lens.i32, halo=0, prec=prec)[:, :, 0].contiguous()  # (B, T)
             frames_pitch = frames_pitch.contiguous()
-            psum = ops.pitch_mse(pp, frames_pitch, lens.i32)
-            terms[6:7] = psum[0] / (psum[1] + 1e-5)
+            psum = ops.pitch_mse(pp, frames_pitch, lens.i32, arena=arena)
             dpp = ops.pitch_grad(pp, frames_pitch, lens.i32, psum, cfg['pcw'])
-            g = torch.zeros(B, T, 4, dtype=torch.float32, device=dev)
+            g = ops._zeros(arena, B, T, 4, device=dev)
             g[:, :, 0] = dpp
             # each input-gradient GEMM applies the previous layer's BatchNorm scale and ReLU mask in its epilogue
             for k in range(len(pitch_layers) - 1, 0, -1):
@@ -124,7 +112,11 @@ class _LossFn(torch.autograd.Function):
                                   relu_aux=acts[k - 1], lens=lens.i32, halo=depth - k + 1, prec=prec)
             d = ops.conv_gemm(g, pitch_layers[0]['pack'], None, transpose=True, lens=lens.i32, halo=0, prec=prec)
             dmel = dmel + ops.transpose(d)
-        total = terms[0] + terms[2] + terms[3] + terms[4] + cfg['ecw'] * terms[5] + cfg['pcw'] * terms[6]
+        # the seven terms, the total and the two small gradients: one launch (was ~30 one-element ATen launches)
+        terms, total, d_spk, d_pm = ops.loss_finalize(ce, dlogits, cfg['spk_weight'], pm, cfg['pmw'], sums, lens.i32, M, cfg['msw'],
+                                                      esum, cfg['ecw'], psum, cfg['pcw'])
+        if d_pm is not None:
+            d_pm = d_pm.view_as(post_multipliers)
         ctx.save_for_backward(dmel, d_spk, d_pm)
         ctx.mark_non_differentiable(terms)
         return total, terms
@@ -133,7 +125,7 @@ class _LossFn(torch.autograd.Function):
     def backward(ctx, g_total, _g_terms):
         dmel, d_spk, d_pm = ctx.saved_tensors
         return (dmel * g_total, None if d_spk is None else d_spk * g_total, None if d_pm is None else d_pm * g_total,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 class DaftExprtLoss(nn.Module):
@@ -185,7 +177,7 @@ class DaftExprtLoss(nn.Module):
         spk_weight = iteration if torch.is_tensor(iteration) else self.update_adversarial_weight(iteration)
         cfg = {'spk_weight': spk_weight, 'pmw': self.post_mult_weight, 'msw': self.mel_spec_weight,
                'ecw': self.energy_consistency_weight, 'pcw': self.pitch_consistency_weight if self.pitch_layers is not None else 0.0}
-        total, terms = _LossFn.apply(mel_preds, speaker_preds, pm, mel_targets, speaker_ids, frames_pitch, lens, cfg, self.pitch_layers)
+        total, terms = _LossFn.apply(mel_preds, speaker_preds, pm, mel_targets, speaker_ids, frames_pitch, lens, cfg, self.pitch_layers, self.runtime)
         return total, LossTerms(terms)
 
 

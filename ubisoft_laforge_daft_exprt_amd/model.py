@@ -184,7 +184,7 @@ class AccentEncoder(nn.Module):
                                    self.pitch_embedding.conv.weight, self.pitch_embedding.conv.bias)
         for block in self.blocks:
             x = block(x, None, lens)
-        return Fx.MeanPoolFn.apply(x, lens)
+        return Fx.MeanPoolFn.apply(x, lens, getattr(self, '_dx_rt', None))
 
 
 class SpeakerClassifier(nn.Module):
@@ -294,7 +294,7 @@ class PhonemeEncoder(nn.Module):
     def forward(self, x, film_params, input_lengths):
         lens = input_lengths if isinstance(input_lengths, Lengths) else Lengths(input_lengths)
         pe = positional_table(self.cfg['hidden_embed_dim'], x.device)
-        h = Fx.EmbedPosFn.apply(x, self.symbols_embedding.weight, pe, lens)
+        h = Fx.EmbedPosFn.apply(x, self.symbols_embedding.weight, pe, lens, getattr(self, '_dx_rt', None))
         film = _film_blocks(film_params)
         for i, block in enumerate(self.blocks):
             h = block(h, None if film is None else film[i], lens)

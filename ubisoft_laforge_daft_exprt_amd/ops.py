@@ -27,6 +27,8 @@ class Runtime:
         self.pack_epoch = 0          # "an optimiser wrote the parameters through raw pointers" (optim.FusedAdam)
         self.sink = False            # backward kernels accumulate straight into pre-zeroed ``param.grad`` (ddp.GradientReducer)
         self.launch_log = None       # bench.py: (kind, ...) records of every launch, to price algorithmic FLOPs / bytes
+        self.arena = None            # ZeroArena of the running training step (trainer.Trainer): one zero fill for all small accumulators
+        self.arena_hint = 1 << 20    # floats; tracks the high-water mark of the previous steps
         self.seed_offset = None      # device int64 scalar added to every dropout seed on the device (graph replays bump it)
         self._packs = []             # weak refs to this runtime's PackedWeight objects (one-launch batched re-pack)
         self._tables = {}
@@ -288,6 +290,7 @@ class ZeroArena:
     def __init__(self, device, n_floats):
         self.buf = torch.zeros(int(n_floats), dtype=torch.float32, device=device)
         self.off = 0
+        self.requested = 0                        # floats asked for, including what did not fit
 
     @staticmethod
     def padded(n):
@@ -297,11 +300,25 @@ class ZeroArena:
         n = 1
         for d in shape:
             n *= int(d)
+        self.requested += self.padded(n)
         if self.off + n > self.buf.numel():
             return torch.zeros(*shape, dtype=torch.float32, device=self.buf.device)
         out = self.buf[self.off:self.off + n].view(*shape)
         self.off += self.padded(n)
         return out
+
+
+def begin_step_arena(rt: Runtime, device) -> None:
+    """One zero-filled buffer for every small accumulator / zero-initialised scratch tensor of the coming step (a training step had
+    ~45 separate 4 us fill launches).  The owner calls ``end_step_arena`` when the step's backward has been issued: code running
+    outside a step never sees a used arena."""
+    rt.arena = ZeroArena(device, rt.arena_hint)
+
+
+def end_step_arena(rt: Runtime) -> None:
+    if rt.arena is not None:
+        rt.arena_hint = max(rt.arena_hint, int(1.25 * rt.arena.requested))
+        rt.arena = None
 
 
 def _zeros(arena, *shape, device=None):
@@ -403,9 +420,9 @@ def mask_rows(x, lens):
     return out
 
 
-def embedding_bwd(dout, sym, lens, n_rows):
+def embedding_bwd(dout, sym, lens, n_rows, arena=None):
     B, N, D = dout.shape
-    demb = torch.zeros(n_rows, D, dtype=torch.float32, device=dout.device)
+    demb = _zeros(arena, n_rows, D, device=dout.device)
     lib().dx_embedding_bwd(_p(dout), _p(sym), _p(lens), _p(demb), B, N, D, _stream())
     return demb
 
@@ -434,9 +451,9 @@ def scalar_conv_wgrad(dout, s0, s1, lens, rowscale=None, sinks=None):
     return tuple(None if sk is not None else t for sk, t in zip(sinks, (dw0, db0, dw1, db1)))
 
 
-def mean_pool(x, lens):
+def mean_pool(x, lens, arena=None):
     B, N, C = x.shape
-    out = torch.zeros(B, C, dtype=torch.float32, device=x.device)
+    out = _zeros(arena, B, C, device=x.device)
     lib().dx_mean_pool(_p(x), _p(lens), _p(out), B, N, C, _stream())
     return out
 
@@ -496,11 +513,11 @@ def upsample_fwd(xs, mu, sigma, lens, T):
     return xup, weights
 
 
-def upsample_bwd(dxup, xs, mu, sigma, weights, lens):
+def upsample_bwd(dxup, xs, mu, sigma, weights, lens, arena=None):
     B, L, D = xs.shape
     T = weights.shape[2]
-    dxs = torch.zeros_like(xs)
-    dsigma = torch.zeros(B, L, dtype=torch.float32, device=xs.device)
+    dxs = _zeros(arena, B, L, D, device=xs.device)
+    dsigma = _zeros(arena, B, L, device=xs.device)
     lib().dx_upsample_bwd(_p(dxup), _p(xs), _p(mu), _p(sigma), _p(weights), _p(lens), _p(dxs), _p(dsigma), B, L, T, D, _stream())
     return dxs, dsigma
 
@@ -517,34 +534,49 @@ def upsample_sym_bwd(dxs, dsigma, xs, z, dur, lens, wd, bd, wr, dwr_sink=None, d
     return dxs_out, dz, (None if dwr_sink is not None else dwr), (None if dbr_sink is not None else dbr)
 
 
-def mel_stats(mel_pred, mel_target):
+def mel_stats(mel_pred, mel_target, arena=None):
     B, M, T = mel_pred.shape
     dev = mel_pred.device
     ep = torch.empty(B, T, dtype=torch.float32, device=dev)
     et = torch.empty(B, T, dtype=torch.float32, device=dev)
-    sums = torch.zeros(2, B, dtype=torch.float32, device=dev)
+    sums = _zeros(arena, 2, B, device=dev)
     lib().dx_mel_stats(_p(mel_pred), _p(mel_target), _p(ep), _p(et), _p(sums[0]), _p(sums[1]), B, M, T, _stream())
     return ep, et, sums
 
 
-def energy_diff(ep, et, lens):
+def energy_diff(ep, et, lens, arena=None):
     B, T = ep.shape
     des = torch.empty_like(ep)
-    esum = torch.zeros(1, dtype=torch.float32, device=ep.device)
+    esum = _zeros(arena, 1, device=ep.device)
     lib().dx_energy_diff(_p(ep), _p(et), _p(lens), _p(des), _p(esum), B, T, _stream())
     return des, esum
 
 
-def mel_grad(mel_pred, mel_target, ep, des, lens, c_l1, c_l2, c_e):
+def mel_grad(mel_pred, mel_target, ep, des, lens, c_l1, c_l2, c_e, e_per_total=False):
     B, M, T = mel_pred.shape
     dmel = torch.empty_like(mel_pred)
-    lib().dx_mel_grad(_p(mel_pred), _p(mel_target), _p(ep), _p(des), _p(lens), float(c_l1), float(c_l2), float(c_e), _p(dmel), B, M, T, _stream())
+    lib().dx_mel_grad(_p(mel_pred), _p(mel_target), _p(ep), _p(des), _p(lens), float(c_l1), float(c_l2), float(c_e), int(e_per_total), _p(dmel),
+                      B, M, T, _stream())
     return dmel
 
 
-def pitch_mse(pp, gt, lens):
+def loss_finalize(ce, dlogits, spk_w, pm, pmw, sums, lens, M, msw, esum, ecw, psum, pcw):
+    """-> (terms[7], total[1], d_spk or None, d_pm or None); ``spk_w``: python float or device scalar tensor"""
+    dev = sums.device
+    B = sums.shape[1]
+    out = torch.empty(8, dtype=torch.float32, device=dev)
+    d_spk = torch.empty_like(dlogits) if dlogits is not None else None
+    d_pm = torch.empty_like(pm) if pm is not None else None
+    w_dev = spk_w if torch.is_tensor(spk_w) else None
+    lib().dx_loss_finalize(_p(ce), _p(w_dev), 0.0 if w_dev is not None else float(spk_w), _p(dlogits), _p(d_spk), 0 if dlogits is None else dlogits.numel(),
+                           _p(pm), _p(d_pm), 0 if pm is None else pm.numel(), float(pmw), _p(sums[0]), _p(sums[1]), _p(lens), B, M, float(msw),
+                           _p(esum), float(ecw), _p(psum), float(pcw), _p(out), _p(out[7:]), _stream())
+    return out[:7], out[7], d_spk, d_pm
+
+
+def pitch_mse(pp, gt, lens, arena=None):
     B, T = gt.shape
-    sums = torch.zeros(2, dtype=torch.float32, device=gt.device)
+    sums = _zeros(arena, 2, device=gt.device)
     lib().dx_pitch_mse(_p(pp), _p(gt), _p(lens), _p(sums), B, T, _stream())
     return sums
 
