@@ -303,7 +303,9 @@ class ZeroArena:
         self.requested += self.padded(n)
         if self.off + n > self.buf.numel():
             return torch.zeros(*shape, dtype=torch.float32, device=self.buf.device)
-        out = self.buf[self.off:self.off + n].view(*shape)
+        # an ALIAS of the buffer's storage, not a view of ``buf``: autograd's view / in-place bookkeeping (shared version counter,
+        # "view created in no_grad mode ... base modified in place") must not couple the unrelated tensors carved out of one arena
+        out = torch.empty(0, dtype=torch.float32, device=self.buf.device).set_(self.buf.untyped_storage(), self.off, tuple(int(d) for d in shape))
         self.off += self.padded(n)
         return out
 
