@@ -11,6 +11,9 @@
  *   - lens[b] (int32, device) = valid rows of batch row b; rows n >= lens[b] are padding
  *   - `stream` is a hipStream_t; all work is enqueued on it, nothing synchronises (graph-capture safe)
  *   - return value: 0 = ok, non-zero = error; dx_last_error() returns the message of the calling thread's last error
+ *   - reduced precision: every entry point with a `bf16` / `*_bf16` argument (and the pack functions) also exists with the suffix
+ *     `_f16` (e.g. dx_conv_gemm_f16): the same kernel built for IEEE fp16 operands and storage (v_mfma_f32_16x16x32_f16), where each
+ *     of those arguments then means "fp16".  BASELINE.json config 2 runs the bf16 build, config 5 the fp16 build.
  *   - dropout: counter-based (seed, element index); the backward entry points regenerate the mask from the same seed.
  *     seed_offset (optional device scalar) is added to the seed(s) on the device: a captured HIP graph draws a new dropout
  *     stream on every replay by bumping that scalar, although the launch arguments are frozen
@@ -159,7 +162,7 @@ int dx_gather_speaker_rows(const float* emb, const long* speaker_ids, const int*
 /* ---- fused optimiser step: train.py:278-280 (Adam), :443 (clip_grad_norm_) ------------------------------ */
 int dx_sumsq(const float* x, long n, float* out, void* stream);
 int dx_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
-                 float weight_decay, int step, const float* normsq, float max_norm, void* stream);
+                 float weight_decay, int step, const float* normsq, float max_norm, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -68,6 +68,9 @@ def _oracle_step(batch, hp, n_threads=None):
                 spk_preds=out[0].detach().numpy())
 
 
+FP16_LOSS_SCALE = 4096.0      # the trainer's static loss scale of the fp16 mode (gradients that live in fp16 tensors would underflow)
+
+
 def _hip_step(pkg, batch, hp, precision):
     pkg.set_precision(precision)
     try:
@@ -79,10 +82,11 @@ def _hip_step(pkg, batch, hp, precision):
         inputs, targets = model.parse_batch(DEV, batch)
         out = model(inputs)
         total, terms = crit(out, targets + (inputs[6], inputs[7]), ITERATION)
-        total.backward()
+        scale = FP16_LOSS_SCALE if precision == 'fp16' else 1.0
+        (total * scale).backward()
         torch.cuda.synchronize()
         return dict(mel=out[3][0].detach().cpu().numpy(), weights=out[4].detach().cpu().numpy(), total=float(total),
-                    terms={k: float(v) for k, v in terms.items()}, grads={k: p.grad.detach().cpu() for k, p in model.named_parameters()},
+                    terms={k: float(v) for k, v in terms.items()}, grads={k: p.grad.detach().cpu() / scale for k, p in model.named_parameters()},
                     spk_preds=out[0].detach().cpu().numpy())
     finally:
         pkg.set_precision('f32')
@@ -136,10 +140,12 @@ def test_c2_f32_forward_loss_gradients_vs_oracle(pkg, c2):
         assert rel < 3e-3 and cos > 0.99999, (k, rel, cos)
 
 
-def test_c2_bf16_forward_loss_gradients_vs_oracle(pkg, c2):
-    """The mode and shape bench.py measures, end to end against the oracle, with the tolerances stated at the top of this file."""
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+def test_c2_bf16_forward_loss_gradients_vs_oracle(pkg, c2, precision):
+    """The mode and shape bench.py measures (bf16) and the fp16 twin of BASELINE.json config 5, end to end against the oracle, with
+    the tolerances stated at the top of this file (fp16 carries 3 more mantissa bits than bf16 and lands well inside them)."""
     hp, batch, ref = c2
-    got = _hip_step(pkg, batch, hp, 'bf16')
+    got = _hip_step(pkg, batch, hp, precision)
     assert got['mel'].shape == ref['mel'].shape
     assert np.isfinite(got['mel']).all() and all(torch.isfinite(g).all() for g in got['grads'].values())
     l1 = valid_mel_l1(got['mel'], ref['mel'], batch[9])
@@ -151,10 +157,10 @@ def test_c2_bf16_forward_loss_gradients_vs_oracle(pkg, c2):
     small = {k: v for k, v in rows.items() if v[2] < 64}
     worst_rel = max(rows.items(), key=lambda kv: kv[1][0])
     worst_cos = min(big.items(), key=lambda kv: kv[1][1])
-    _dump('parity_c2_bf16.json', {'mel_l1': l1, 'loss_terms_rel': term_err, 'loss_total': [got['total'], ref['total']],
+    _dump(f'parity_c2_{precision}.json', {'mel_l1': l1, 'loss_terms_rel': term_err, 'loss_total': [got['total'], ref['total']],
                                   'worst_grad_rel': [worst_rel[0], worst_rel[1][0]], 'worst_grad_cos': [worst_cos[0], worst_cos[1][1]],
                                   'grads': {k: [v[0], v[1]] for k, v in rows.items()}})
-    print(f'C2 bf16: valid mel L1 {l1:.3e}; loss total {got["total"]:.5f} vs {ref["total"]:.5f}; worst term rel {max(term_err.values()):.3e}; '
+    print(f'C2 {precision}: valid mel L1 {l1:.3e}; loss total {got["total"]:.5f} vs {ref["total"]:.5f}; worst term rel {max(term_err.values()):.3e}; '
           f'worst grad rel {worst_rel[1][0]:.3e} ({worst_rel[0]}); worst grad cos {worst_cos[1][1]:.5f} ({worst_cos[0]})')
     assert l1 < BF16_MEL_L1, l1
     assert abs(got['total'] - ref['total']) <= BF16_LOSS_REL * abs(ref['total'])
@@ -176,7 +182,7 @@ def _c4(device):
     return tuple(mv(t) for t in inputs), {k: mv(v) for k, v in prosody.items()}, mv(spk), mv(accent)
 
 
-@pytest.mark.parametrize('precision,tol', [('f32', 2e-5), ('bf16', BF16_MEL_L1)])
+@pytest.mark.parametrize('precision,tol', [('f32', 2e-5), ('bf16', BF16_MEL_L1), ('fp16', BF16_MEL_L1)])
 def test_c4_inference_b256_vs_oracle(pkg, precision, tol):
     from oracle import daft_exprt_oracle as oracle
     from ubisoft_laforge_daft_exprt_amd.inference import GraphedSynthesizer

@@ -62,7 +62,14 @@ class _Lib:
                 '(hipcc --offload-arch=gfx950). There is no fallback path.')
         self._dll = ctypes.CDLL(LIB_PATH)
         self._last_error = None
-        for name, (restype, argtypes, argnames) in parse_header(with_names=True).items():
+        protos = parse_header(with_names=True)
+        # fp16 twins (csrc/dx_f16_names.h): the same entry points compiled with fp16 in place of bf16, suffix _f16
+        f16 = os.path.join(PKG, 'csrc', 'dx_f16_names.h')
+        if os.path.exists(f16):
+            for base in re.findall(r'#define (dx_\w+) \1_f16', open(f16).read()):
+                if base in protos and hasattr(self._dll, base + '_f16'):
+                    protos[base + '_f16'] = protos[base]
+        for name, (restype, argtypes, argnames) in protos.items():
             fn = getattr(self._dll, name)  # AttributeError if the header and the library disagree
             fn.restype = restype
             fn.argtypes = argtypes

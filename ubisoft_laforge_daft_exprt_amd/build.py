@@ -10,6 +10,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(PKG, 'libdaft_exprt_hip.so')
 SOURCES = ['dx_runtime.hip', 'dx_gemm.hip', 'dx_ffpair.hip', 'dx_attention.hip', 'dx_rows.hip', 'dx_upsample.hip', 'dx_loss.hip', 'dx_optim.hip']
+F16_SOURCES = ['dx_gemm.hip', 'dx_ffpair.hip', 'dx_attention.hip', 'dx_rows.hip']    # compiled a second time with -DDX_F16 (fp16 operand mode)
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wno-unused-value', '-Wno-unused-result']
 
 
@@ -20,22 +21,24 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src):
-    obj = os.path.join(CSRC, os.path.splitext(src)[0] + '.o')
-    deps = [os.path.join(CSRC, src), os.path.join(CSRC, 'dx_common.h')]
+def _compile(job):
+    src, f16 = job
+    obj = os.path.join(CSRC, os.path.splitext(src)[0] + ('_f16.o' if f16 else '.o'))
+    deps = [os.path.join(CSRC, src), os.path.join(CSRC, 'dx_common.h'), os.path.join(CSRC, 'dx_f16_names.h')]
     if _stale(obj, deps):
-        subprocess.run(['hipcc', *FLAGS, '-c', os.path.join(CSRC, src), '-o', obj], check=True)
+        subprocess.run(['hipcc', *FLAGS, *(['-DDX_F16'] if f16 else []), '-c', os.path.join(CSRC, src), '-o', obj], check=True)
     return obj
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    jobs = [(src, False) for src in SOURCES] + [(src, True) for src in F16_SOURCES]
     if force:
-        for src in SOURCES:
-            obj = os.path.join(CSRC, os.path.splitext(src)[0] + '.o')
+        for src, f16 in jobs:
+            obj = os.path.join(CSRC, os.path.splitext(src)[0] + ('_f16.o' if f16 else '.o'))
             if os.path.exists(obj):
                 os.remove(obj)
-    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as pool:
-        objs = list(pool.map(_compile, SOURCES))
+    with ThreadPoolExecutor(max_workers=6) as pool:
+        objs = list(pool.map(_compile, jobs))
     if _stale(LIB, objs):
         subprocess.run(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB, *objs], check=True)
     if verbose:

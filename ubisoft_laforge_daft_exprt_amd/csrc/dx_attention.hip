@@ -398,7 +398,7 @@ __device__ __forceinline__ void stage_tile_bf16(unsigned char* dst, const float*
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r0 + row < N) v = *reinterpret_cast<const float4*>(base + (size_t)(r0 + row) * ld + col0 + q * 4);
     bf16x4 h;
-    h[0] = (__bf16)(v.x * scale); h[1] = (__bf16)(v.y * scale); h[2] = (__bf16)(v.z * scale); h[3] = (__bf16)(v.w * scale);
+    h[0] = (dx_h16)(v.x * scale); h[1] = (dx_h16)(v.y * scale); h[2] = (dx_h16)(v.z * scale); h[3] = (dx_h16)(v.w * scale);
     *reinterpret_cast<uint2*>(dst + sw_off(row, q >> 1) + ((q & 1) << 3)) = __builtin_bit_cast(uint2, h);
   }
 }
@@ -429,7 +429,7 @@ __device__ __forceinline__ void stage_tile_bf16(unsigned char* dst, const float*
       const int u_ = tid + it * 256;                                                                              \
       const int row_ = u_ >> 4, q_ = u_ & 15;                                                                     \
       bf16x4 h_;                                                                                                  \
-      h_[0] = (__bf16)REG[it][0]; h_[1] = (__bf16)REG[it][1]; h_[2] = (__bf16)REG[it][2]; h_[3] = (__bf16)REG[it][3]; \
+      h_[0] = (dx_h16)REG[it][0]; h_[1] = (dx_h16)REG[it][1]; h_[2] = (dx_h16)REG[it][2]; h_[3] = (dx_h16)REG[it][3]; \
       *reinterpret_cast<uint2*>((DST) + sw_off(row_, q_ >> 1) + ((q_ & 1) << 3)) = __builtin_bit_cast(uint2, h_); \
     }                                                                                                             \
   } else {                                                                                                        \
@@ -458,32 +458,32 @@ __device__ __forceinline__ bf16x8 tr_pair(const unsigned char* tile, int rowA, i
 }
 __device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {
   bf16x8 h;
-  h[0] = (__bf16)a[0]; h[1] = (__bf16)a[1]; h[2] = (__bf16)a[2]; h[3] = (__bf16)a[3];
-  h[4] = (__bf16)b[0]; h[5] = (__bf16)b[1]; h[6] = (__bf16)b[2]; h[7] = (__bf16)b[3];
+  h[0] = (dx_h16)a[0]; h[1] = (dx_h16)a[1]; h[2] = (dx_h16)a[2]; h[3] = (dx_h16)a[3];
+  h[4] = (dx_h16)b[0]; h[5] = (dx_h16)b[1]; h[6] = (dx_h16)b[2]; h[7] = (dx_h16)b[3];
   return h;
 }
 // 8 consecutive fp32 values of a global row -> bf16x8 (scaled)
 __device__ __forceinline__ bf16x8 load_row8(const float* p, float scale) {
   const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
   bf16x8 h;
-  h[0] = (__bf16)(a.x * scale); h[1] = (__bf16)(a.y * scale); h[2] = (__bf16)(a.z * scale); h[3] = (__bf16)(a.w * scale);
-  h[4] = (__bf16)(b.x * scale); h[5] = (__bf16)(b.y * scale); h[6] = (__bf16)(b.z * scale); h[7] = (__bf16)(b.w * scale);
+  h[0] = (dx_h16)(a.x * scale); h[1] = (dx_h16)(a.y * scale); h[2] = (dx_h16)(a.z * scale); h[3] = (dx_h16)(a.w * scale);
+  h[4] = (dx_h16)(b.x * scale); h[5] = (dx_h16)(b.y * scale); h[6] = (dx_h16)(b.z * scale); h[7] = (dx_h16)(b.w * scale);
   return h;
 }
-__device__ __forceinline__ bf16x8 load_row8(const __bf16* p, float scale) {
+__device__ __forceinline__ bf16x8 load_row8(const dx_h16* p, float scale) {
   bf16x8 h = *reinterpret_cast<const bf16x8*>(p);
   if (scale != 1.f) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) h[e] = (__bf16)((float)h[e] * scale);
+    for (int e = 0; e < 8; ++e) h[e] = (dx_h16)((float)h[e] * scale);
   }
   return h;
 }
 __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
-__device__ __forceinline__ void store4(__bf16* p, float a, float b, float c, float d) {
-  bf16x4 h; h[0] = (__bf16)a; h[1] = (__bf16)b; h[2] = (__bf16)c; h[3] = (__bf16)d;
+__device__ __forceinline__ void store4(dx_h16* p, float a, float b, float c, float d) {
+  bf16x4 h; h[0] = (dx_h16)a; h[1] = (dx_h16)b; h[2] = (dx_h16)c; h[3] = (dx_h16)d;
   *reinterpret_cast<bf16x4*>(p) = h;
 }
-#define DX_MFMA_BF16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A), (B), (C), 0, 0, 0)
+#define DX_MFMA_BF16(A, B, C) DX_MFMA_H16((A), (B), (C))
 
 template <typename QT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a_) {
@@ -619,8 +619,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
     const float4 g0 = *reinterpret_cast<const float4*>(a.dctx + o), g1 = *reinterpret_cast<const float4*>(a.dctx + o + 4);
     const float4 c0 = *reinterpret_cast<const float4*>(a.ctx + o), c1 = *reinterpret_cast<const float4*>(a.ctx + o + 4);
     bf16x8 hg;
-    hg[0] = (__bf16)g0.x; hg[1] = (__bf16)g0.y; hg[2] = (__bf16)g0.z; hg[3] = (__bf16)g0.w;
-    hg[4] = (__bf16)g1.x; hg[5] = (__bf16)g1.y; hg[6] = (__bf16)g1.z; hg[7] = (__bf16)g1.w;
+    hg[0] = (dx_h16)g0.x; hg[1] = (dx_h16)g0.y; hg[2] = (dx_h16)g0.z; hg[3] = (dx_h16)g0.w;
+    hg[4] = (dx_h16)g1.x; hg[5] = (dx_h16)g1.y; hg[6] = (dx_h16)g1.z; hg[7] = (dx_h16)g1.w;
     gf[ks] = hg;
     delta_q += (g0.x * c0.x + g0.y * c0.y) + (g0.z * c0.z + g0.w * c0.w) + (g1.x * c1.x + g1.y * c1.y) + (g1.z * c1.z + g1.w * c1.w);
   }
@@ -842,7 +842,7 @@ int dx_attention_fwd(const void* qkvv, int ld, const int* lens, float* ctx, int 
   AttnArgs a{qkv, ld, lens, ctx, ldc, lse, B, N, H, D, seed, (uint32_t)lrintf(p_drop * 65536.f), 1.f / (1.f - p_drop), seed_offset};
   hipStream_t s = (hipStream_t)stream;
   dx_prof_begin(DX_PROF_ATTN_FWD, s);
-  if (bf16 && qkv_bf16) hipLaunchKernelGGL(attn_fwd_bf16_kernel<__bf16>, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
+  if (bf16 && qkv_bf16) hipLaunchKernelGGL(attn_fwd_bf16_kernel<dx_h16>, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
   else if (bf16) hipLaunchKernelGGL(attn_fwd_bf16_kernel<float>, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(attn_fwd_kernel, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
   dx_prof_end(DX_PROF_ATTN_FWD, s);
@@ -872,9 +872,9 @@ int dx_attention_bwd(const void* qkvv, int ld, const float* ctx, const float* dc
 #define DX_ATTN_BWD(QT_, OT_)                                                                          \
     hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<QT_, OT_>), grid, dim3(256), 0, s, a);                 \
     hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<QT_, OT_>), grid, dim3(256), 0, s, a);
-    if (qkv_bf16 && dqkv_bf16) { DX_ATTN_BWD(__bf16, __bf16) }
-    else if (qkv_bf16) { DX_ATTN_BWD(__bf16, float) }
-    else if (dqkv_bf16) { DX_ATTN_BWD(float, __bf16) }
+    if (qkv_bf16 && dqkv_bf16) { DX_ATTN_BWD(dx_h16, dx_h16) }
+    else if (qkv_bf16) { DX_ATTN_BWD(dx_h16, float) }
+    else if (dqkv_bf16) { DX_ATTN_BWD(float, dx_h16) }
     else { DX_ATTN_BWD(float, float) }
 #undef DX_ATTN_BWD
   } else {

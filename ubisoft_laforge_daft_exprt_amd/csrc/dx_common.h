@@ -40,8 +40,20 @@ enum { DX_PROF_CONV_GEMM = 0, DX_PROF_WGRAD_GEMM = 1, DX_PROF_ATTN_FWD = 2, DX_P
        DX_PROF_UPSAMPLE = 4, DX_PROF_ROWS = 5, DX_PROF_NKINDS = 6 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// The 16-bit operand / storage type of the reduced-precision paths.  dx_gemm.hip, dx_ffpair.hip, dx_attention.hip and dx_rows.hip are
+// compiled TWICE: as they stand (bf16: BASELINE.json config 2) and with -DDX_F16 (IEEE fp16: config 5), where every exported name
+// gets the suffix _f16 (dx_f16_names.h) and every "bf16" flag / argument of the C ABI means "fp16".  Same kernels, same layouts,
+// v_mfma_f32_16x16x32_f16 instead of _bf16.  (The vector typedefs keep their historic names.)
+#ifdef DX_F16
+typedef _Float16 dx_h16;
+#define DX_MFMA_H16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_f16((A), (B), (C), 0, 0, 0)
+#include "dx_f16_names.h"
+#else
+typedef __bf16 dx_h16;
+#define DX_MFMA_H16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16((A), (B), (C), 0, 0, 0)
+#endif
+typedef dx_h16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef dx_h16 bf16x4 __attribute__((ext_vector_type(4)));
 
 static inline int dx_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int dx_roundup(int a, int b) { return dx_cdiv(a, b) * b; }

@@ -36,11 +36,11 @@ constexpr int FP_HR = 130;       // rows of an LDS activation image (x: 130 used
 constexpr int FP_IMG = 2 * FP_HR * 128;   // bytes of one image: [2 chunks of 64 channels][130 rows][128 B]
 
 struct FFPairArgs {
-  const __bf16* X; int ldx;
-  const __bf16* Wa; const __bf16* Wb;
+  const dx_h16* X; int ldx;
+  const dx_h16* Wa; const dx_h16* Wb;
   const float* bias_a; const float* bias_b;
-  const __bf16* aux; int ld_aux;
-  __bf16* H; int ldh;
+  const dx_h16* aux; int ld_aux;
+  dx_h16* H; int ldh;
   float* Y; int ldy;
   int B, N, F;
   int accumulate;
@@ -58,7 +58,7 @@ __device__ __forceinline__ int fp_lds_off(int row, int slot) { return row * 128 
 
 __device__ __forceinline__ uint2 fp_pack4(float a, float b, float c, float d) {
   bf16x4 h;
-  h[0] = (__bf16)a; h[1] = (__bf16)b; h[2] = (__bf16)c; h[3] = (__bf16)d;
+  h[0] = (dx_h16)a; h[1] = (dx_h16)b; h[2] = (dx_h16)c; h[3] = (dx_h16)d;
   return __builtin_bit_cast(uint2, h);
 }
 
@@ -82,7 +82,7 @@ __device__ __forceinline__ int fp_wave_sum_i(int v) {
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
-#define FP_MMA(W, X, C) C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W), __builtin_bit_cast(bf16x8, X), C, 0, 0, 0);
+#define FP_MMA(W, X, C) C = DX_MFMA_H16(__builtin_bit_cast(bf16x8, W), __builtin_bit_cast(bf16x8, X), C);
 
 // AUX: backward (mid = sign mask of the stored forward activation); RELU: forward (mid = ReLU)
 template <bool AUX, bool RELU>
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
   // ---- weight fragment stream of this wave: step s of slice f = (tap = s / 4, ks = s % 4), two fragments (row blocks i = 0, 1) ----
   // producer: Wa pack [3][F rows][128 k]:  block ((tap * F/16 + f*8 + 2 wq + i) * 4 + ks)
   // consumer: Wb pack [3][128 rows][F k]:  block ((tap * 8 + 2 wq + i) * F/32 + f*4 + ks)
-  const __bf16* const wbase = role == 0 ? a.Wa + (size_t)(2 * wq) * 4 * 512
+  const dx_h16* const wbase = role == 0 ? a.Wa + (size_t)(2 * wq) * 4 * 512
                                         : a.Wb + (size_t)(2 * wq) * (a.F >> 5) * 512;       // wave-uniform: scalar registers
   const unsigned lane16 = lane * 16;                  // + a 32-bit per-lane byte offset: global_load with a scalar base
   const int w_tap = role == 0 ? (a.F >> 4) * 4 * 512 : 8 * (a.F >> 5) * 512;      // elements between taps
@@ -451,8 +451,8 @@ int dx_ff_pair(const void* X, int ldx, const void* Wa, const void* Wb, const flo
   DX_REQUIRE(skip_halo < 0 || lens, "dx_ff_pair: skip_halo needs lens");
   DX_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)Wa % 16) == 0 && ((uintptr_t)Wb % 16) == 0 && ((uintptr_t)H % 16) == 0 &&
              ((uintptr_t)Y % 16) == 0 && ((uintptr_t)aux % 8) == 0, "dx_ff_pair: pointers must be 16-byte aligned");
-  FFPairArgs a{(const __bf16*)X, ldx, (const __bf16*)Wa, (const __bf16*)Wb, bias_a, bias_b, (const __bf16*)aux, ld_aux,
-               (__bf16*)H, ldh, Y, ldy, B, N, F, accumulate, lens, skip_halo, nullptr};
+  FFPairArgs a{(const dx_h16*)X, ldx, (const dx_h16*)Wa, (const dx_h16*)Wb, bias_a, bias_b, (const dx_h16*)aux, ld_aux,
+               (dx_h16*)H, ldh, Y, ldy, B, N, F, accumulate, lens, skip_halo, nullptr};
 #ifdef DX_FFPAIR_STAMPS
   a.stamps = g_ffpair_stamps;
 #endif

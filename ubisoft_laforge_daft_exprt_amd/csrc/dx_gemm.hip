@@ -56,21 +56,21 @@ template <> struct Mma<float> {
     c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
   }
 };
-template <> struct Mma<__bf16> {
+template <> struct Mma<dx_h16> {
   static __device__ __forceinline__ void run(const float4& a, const float4& b, f32x4& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    c = DX_MFMA_H16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c);
   }
 };
 
 __device__ __forceinline__ uint2 pack_bf16x4v(const f32x4& v) {
   bf16x4 h;
-  h[0] = (__bf16)v[0]; h[1] = (__bf16)v[1]; h[2] = (__bf16)v[2]; h[3] = (__bf16)v[3];
+  h[0] = (dx_h16)v[0]; h[1] = (dx_h16)v[1]; h[2] = (dx_h16)v[2]; h[3] = (dx_h16)v[3];
   return __builtin_bit_cast(uint2, h);
 }
 
 __device__ __forceinline__ uint2 pack_bf16x4(const float4& v) {
   bf16x4 h;
-  h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+  h[0] = (dx_h16)v.x; h[1] = (dx_h16)v.y; h[2] = (dx_h16)v.z; h[3] = (dx_h16)v.w;
   return __builtin_bit_cast(uint2, h);
 }
 
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
         const int n = n0 + row, co = co0 + q * 4;
         if (n < a.N && co < a.Cout) {
           if (a.y_bf16) {
-            __bf16* dst = reinterpret_cast<__bf16*>(a.Y) + ((size_t)b * a.N + n) * a.ldy + co;
+            dx_h16* dst = reinterpret_cast<dx_h16*>(a.Y) + ((size_t)b * a.N + n) * a.ldy + co;
             *reinterpret_cast<uint2*>(dst) = make_uint2(0u, 0u);       // bf16 outputs always have Cout % 4 == 0
           } else {
             float* dst = a.Y + ((size_t)b * a.N + n) * a.ldy + co;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
       const int n = n0 + row - PAD, ci = ci0_ + q * XE;                                                                          \
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                                                       \
       if (u < XROWS * XU && n >= 0 && n < a.N && ci < a.Cin) {                                                                   \
-        if constexpr (XH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.X) + ((size_t)b * a.N + n) * a.ldx + ci); \
+        if constexpr (XH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const dx_h16*>(a.X) + ((size_t)b * a.N + n) * a.ldx + ci); \
         else v = *reinterpret_cast<const f32x4*>(a.X + ((size_t)b * a.N + n) * a.ldx + ci);                                      \
       }                                                                                                                          \
       xreg[it] = v;                                                                                                              \
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
       }
       if (a.relu_aux) {
         if (a.aux_bf16) {
-          const bf16x4 av = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.relu_aux) + row * a.ld_aux + co);
+          const bf16x4 av = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const dx_h16*>(a.relu_aux) + row * a.ld_aux + co);
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (!((float)av[e] > 0.f)) v[e] = 0.f;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
       }
       if (a.mask_rows && n >= len_b) { v[0] = v[1] = v[2] = v[3] = 0.f; }
       if (a.y_bf16) {
-        __bf16* dsth = reinterpret_cast<__bf16*>(a.Y) + row * a.ldy + co;
+        dx_h16* dsth = reinterpret_cast<dx_h16*>(a.Y) + row * a.ldy + co;
         *reinterpret_cast<uint2*>(dsth) = pack_bf16x4(make_float4(v[0], v[1], v[2], v[3]));
         continue;
       }
@@ -319,12 +319,12 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, i
   const int wc = wave >> 1, wt = wave & 1;                 // 4 x 2 waves: 32 channels x 64 tokens each
   const int r = lane & 15, g = lane >> 4;
   const int co0 = blockIdx.y * TILE;
-  const __bf16* Wp = reinterpret_cast<const __bf16*>(a.Wp);
+  const dx_h16* Wp = reinterpret_cast<const dx_h16*>(a.Wp);
 
   // weight slice -> LDS, once
   for (int u = tid; u < W_ROWS * 8; u += 512) {
     int row, q;
-    w_unit<__bf16>(u, row, q);
+    w_unit<dx_h16>(u, row, q);
     const int ch = row / (TAPS * TILE), rem = row - ch * (TAPS * TILE);
     const int tap = rem >> 7, col = rem & (TILE - 1);
     *reinterpret_cast<f32x4*>(Ws + lds_off(row, q)) = *reinterpret_cast<const f32x4*>(Wp + wb_off(tap, co0 + col, ch * 64 + q * 8, a.CoutP, a.CinP));
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, i
       const int row = u >> 5, q = u & 31;
       const int n = n0 + row, co = co0 + q * 4;
       if (n < a.N && co < a.Cout) {
-        if (a.y_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.Y) + ((size_t)b * a.N + n) * a.ldy + co) = make_uint2(0u, 0u);
+        if (a.y_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<dx_h16*>(a.Y) + ((size_t)b * a.N + n) * a.ldy + co) = make_uint2(0u, 0u);
         else {
           float* dst = a.Y + ((size_t)b * a.N + n) * a.ldy + co;
           if (co + 3 < a.Cout) *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, i
     const int n = (N0_) + row - PAD, ci = q * XE;                                                                    \
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                                             \
     if (u < XROWS * XU && n >= 0 && n < a.N && ci < a.Cin) {                                                         \
-      if constexpr (XH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.X) + ((size_t)(B_) * a.N + n) * a.ldx + ci); \
+      if constexpr (XH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const dx_h16*>(a.X) + ((size_t)(B_) * a.N + n) * a.ldx + ci); \
       else v = *reinterpret_cast<const f32x4*>(a.X + ((size_t)(B_) * a.N + n) * a.ldx + ci);                         \
     }                                                                                                                \
     xreg[it] = v;                                                                                                    \
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, i
         const int u = tid + it * 512;
         const int n = cn0 + (u >> 4), co = co0 + (u & 15) * 8;
         bf16x8 v = bf16x8{};
-        if (n < a.N && co < a.Cout) v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.relu_aux) + ((size_t)cb * a.N + n) * a.ld_aux + co);
+        if (n < a.N && co < a.Cout) v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const dx_h16*>(a.relu_aux) + ((size_t)cb * a.N + n) * a.ld_aux + co);
         auxreg[it] = v;
       }
     }
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, i
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) Mma<__bf16>::run(wf[i], xf[j], acc[i][j]);
+            for (int j = 0; j < 4; ++j) Mma<dx_h16>::run(wf[i], xf[j], acc[i][j]);
         }
 
     const int len_b = a.lens ? a.lens[cb] : a.N;
@@ -536,22 +536,22 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, i
             if (a.aux_bf16) {
               bf16x8 av;
               if constexpr (TAPS == 3) av = auxreg[it];
-              else av = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.relu_aux) + grow * a.ld_aux + co);
+              else av = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const dx_h16*>(a.relu_aux) + grow * a.ld_aux + co);
 #pragma unroll
               for (int e = 0; e < 8; ++e)
-                if (!((float)av[e] > 0.f)) o[e] = (__bf16)0.f;
+                if (!((float)av[e] > 0.f)) o[e] = (dx_h16)0.f;
             } else {
 #pragma unroll
               for (int e = 0; e < 8; ++e)
-                if (!(a.relu_aux[grow * a.ld_aux + co + e] > 0.f)) o[e] = (__bf16)0.f;
+                if (!(a.relu_aux[grow * a.ld_aux + co + e] > 0.f)) o[e] = (dx_h16)0.f;
             }
           }
           if (a.mask_rows && n >= len_b) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (__bf16)0.f;
+            for (int e = 0; e < 8; ++e) o[e] = (dx_h16)0.f;
           }
-          if (co + 7 < a.Cout) *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(a.Y) + grow * a.ldy + co) = o;
-          else *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.Y) + grow * a.ldy + co) = bf16x4{o[0], o[1], o[2], o[3]};
+          if (co + 7 < a.Cout) *reinterpret_cast<bf16x8*>(reinterpret_cast<dx_h16*>(a.Y) + grow * a.ldy + co) = o;
+          else *reinterpret_cast<bf16x4*>(reinterpret_cast<dx_h16*>(a.Y) + grow * a.ldy + co) = bf16x4{o[0], o[1], o[2], o[3]};
         }
       }
       continue;                                            // the loop-top barrier orders these LDS reads before the next tile's stores
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, i
         }
         if (a.relu_aux) {
           if (a.aux_bf16) {
-            const bf16x4 av = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.relu_aux) + row * a.ld_aux + co);
+            const bf16x4 av = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const dx_h16*>(a.relu_aux) + row * a.ld_aux + co);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               if (!((float)av[e] > 0.f)) v[e] = 0.f;
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, i
         }
         if (a.mask_rows && n >= len_b) { v[0] = v[1] = v[2] = v[3] = 0.f; }
         if (a.y_bf16) {
-          *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.Y) + row * a.ldy + co) = pack_bf16x4(make_float4(v[0], v[1], v[2], v[3]));
+          *reinterpret_cast<uint2*>(reinterpret_cast<dx_h16*>(a.Y) + row * a.ldy + co) = pack_bf16x4(make_float4(v[0], v[1], v[2], v[3]));
           continue;
         }
         float* dst = a.Y + row * a.ldy + co;
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(512) void conv_dk_kernel(const ConvGemmArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // scalar: everything per-wave below stays in SGPRs
   const int kg = wave >> 2, wq = wave & 3;          // waves w and w+4 share a SIMD: one of each K group
   const int r = lane & 15, g = lane >> 4;
-  const __bf16* Wp = reinterpret_cast<const __bf16*>(a.Wp);
+  const dx_h16* Wp = reinterpret_cast<const dx_h16*>(a.Wp);
 
   // Workgroup -> token tile.  A workgroup fills a CU (registers), so a launch with about as many live tiles as CUs must not
   // lose a CU to a padding tile: with tile skipping on, the live tiles of the batch are numbered first (workgroups go to the
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(512) void conv_dk_kernel(const ConvGemmArgs a) {
         const int row = u >> 5, q = u & 31;
         const int n = n0 + row, co = co0 + q * 4;
         if (n < a.N && co < a.Cout) {
-          if (a.y_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.Y) + ((size_t)b * a.N + n) * a.ldy + co) = make_uint2(0u, 0u);
+          if (a.y_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<dx_h16*>(a.Y) + ((size_t)b * a.N + n) * a.ldy + co) = make_uint2(0u, 0u);
           else {
             float* dst = a.Y + ((size_t)b * a.N + n) * a.ldy + co;
             if (co + 3 < a.Cout) *reinterpret_cast<float4*>(dst) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -741,14 +741,14 @@ __global__ __launch_bounds__(512) void conv_dk_kernel(const ConvGemmArgs a) {
   }
   const bool edge_tile = n0 < PAD || n0 + TOK + PAD > a.N;          // wave-uniform
   // fragment (tap, i) of stage ch: element offset wbase + ((tap * (CoutP/16) + i) * (CinP/32) + 2 * ch) * 512
-  const __bf16* const wwave = Wp + ((size_t)((co0 >> 4) + wq * 2) * (a.CinP >> 5) + kg) * 512;      // wave-uniform
+  const dx_h16* const wwave = Wp + ((size_t)((co0 >> 4) + wq * 2) * (a.CinP >> 5) + kg) * 512;      // wave-uniform
   const size_t wtap = (size_t)(a.CoutP >> 4) * (a.CinP >> 5) * 512, wrow = (size_t)(a.CinP >> 5) * 512;
   const int wlane = lane * 8;
   f32x4 wa[NW], wb[NW], xa[X_IT], xb[XH ? X_IT : 1];
   // chunk indices past the end re-read the last chunk (never consumed)
 #define DK_LOAD_W2(TAP, CH, WR)                                                                                      \
   {                                                                                                                  \
-    const __bf16* wp_ = wwave + (size_t)min((CH), nchunks - 1) * 1024 + (TAP) * wtap;                                \
+    const dx_h16* wp_ = wwave + (size_t)min((CH), nchunks - 1) * 1024 + (TAP) * wtap;                                \
     WR[(TAP) * 2] = *reinterpret_cast<const f32x4*>(wp_ + wlane);                                                    \
     WR[(TAP) * 2 + 1] = *reinterpret_cast<const f32x4*>(wp_ + wrow + wlane);                                         \
   }
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(512) void conv_dk_kernel(const ConvGemmArgs a) {
 #define DK_LOAD_X1(IT, CH, XR)                                                                                       \
   {                                                                                                                  \
     const int ch_ = min((CH), nchunks - 1) * 64;                                                                     \
-    if constexpr (XH) XR[IT] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.X) + ch_ + xoff[IT]); \
+    if constexpr (XH) XR[IT] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const dx_h16*>(a.X) + ch_ + xoff[IT]); \
     else XR[IT] = *reinterpret_cast<const f32x4*>(a.X + ch_ + xoff[IT]);                                             \
   }
 #define DK_LOAD_X(CH, XR) { _Pragma("unroll") for (int it = 0; it < X_IT; ++it) DK_LOAD_X1(it, CH, XR) }
@@ -777,7 +777,7 @@ __global__ __launch_bounds__(512) void conv_dk_kernel(const ConvGemmArgs a) {
   const int xfrag1 = lds_off(r + 1, kg * 4 + g);
   const int xfrag2 = lds_off(r + 2, kg * 4 + g);
 #define DK_FRAG(P) (*reinterpret_cast<const float4*>(P))
-#define DK_MMA(W, X, C) C = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W), __builtin_bit_cast(bf16x8, X), C, 0, 0, 0);
+#define DK_MMA(W, X, C) C = DX_MFMA_H16(__builtin_bit_cast(bf16x8, W), __builtin_bit_cast(bf16x8, X), C);
   // One stage of the K loop.  Stamps of the plain order (stage activations, request loads, 48 MFMAs per wave, barrier) gave
   // 2.8 k cycles per stage: 1.75 k with both waves of a SIMD in their MFMAs (18 cycles each) and 1.05 k with both of them
   // stuck ISSUING memory instructions (the CU's address path takes a 1 KB wave-load per 16 cycles: 72 loads = 1.15 k cycles
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(512) void conv_dk_kernel(const ConvGemmArgs a) {
       }
       if (a.relu_aux) {
         if (a.aux_bf16) {
-          const bf16x4 av = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.relu_aux) + row * a.ld_aux + co);
+          const bf16x4 av = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const dx_h16*>(a.relu_aux) + row * a.ld_aux + co);
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (!((float)av[e] > 0.f)) v[e] = 0.f;
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(512) void conv_dk_kernel(const ConvGemmArgs a) {
       }
       if (a.mask_rows && n >= len_b) { v[0] = v[1] = v[2] = v[3] = 0.f; }
       if (a.y_bf16) {
-        *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.Y) + row * a.ldy + co) = pack_bf16x4(make_float4(v[0], v[1], v[2], v[3]));
+        *reinterpret_cast<uint2*>(reinterpret_cast<dx_h16*>(a.Y) + row * a.ldy + co) = pack_bf16x4(make_float4(v[0], v[1], v[2], v[3]));
         continue;
       }
       float* dst = a.Y + row * a.ldy + co;
@@ -1108,10 +1108,10 @@ struct WgradBf16Args {
   float* dbias;
 };
 
-__device__ __forceinline__ bf16x8 tr_fragment(const __bf16* tile, int row0, int col0, int lane) {
+__device__ __forceinline__ bf16x8 tr_fragment(const dx_h16* tile, int row0, int col0, int lane) {
   // rows row0 + 8g + [0,8), columns col0 + [0,16): lane (r = lane & 15, g = lane >> 4) gets column r, rows 8g..8g+7
   const int li = lane & 15, g = lane >> 4, q = li >> 2, p = li & 3;
-  const __bf16* a0 = tile + (row0 + 8 * g + q) * WB_LD + col0 + 4 * p;
+  const dx_h16* a0 = tile + (row0 + 8 * g + q) * WB_LD + col0 + 4 * p;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * WB_LD));
   typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -1140,9 +1140,9 @@ __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel
   // ONE LDS array: the dY tile, the X tile (rows beyond the halo stay zero so every tr read is in bounds), and - after the chunk
   // loop - the fp32 staging tile of the epilogue
   constexpr int SMEM_BYTES = (2 * WB_BK + 8) * WB_LD * 2;
-  __shared__ __attribute__((aligned(16))) __bf16 smem_all[(2 * WB_BK + 8) * WB_LD];
-  __bf16* const Ds = smem_all;
-  __bf16* const Xs = smem_all + WB_BK * WB_LD;
+  __shared__ __attribute__((aligned(16))) dx_h16 smem_all[(2 * WB_BK + 8) * WB_LD];
+  dx_h16* const Ds = smem_all;
+  dx_h16* const Xs = smem_all + WB_BK * WB_LD;
   const int ci_tiles = (a.Cin + CI_T - 1) / CI_T;
   const int co0 = (blockIdx.x / ci_tiles) * TILE;
   const int ci0 = (blockIdx.x % ci_tiles) * CI_T;
@@ -1159,7 +1159,7 @@ __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int u = tid; u < 8 * WB_LD; u += NT) Xs[WB_BK * WB_LD + u] = (__bf16)0.f;
+  for (int u = tid; u < 8 * WB_LD; u += NT) Xs[WB_BK * WB_LD + u] = (dx_h16)0.f;
 
   // Fused bias gradient (column sums of the dY tile), done by the workgroups of input-channel tile 0 with ALL their threads
   // (thread = channel pair x one slice of the rows, 4-byte LDS reads).  As 128 threads x 64 two-byte reads it made those
@@ -1193,7 +1193,7 @@ __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel
     _Pragma("unroll") for (int it = 0; it < D_IT; ++it) {                                                                     \
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                                                    \
       if (drow[it] < dlim_) {                                                                                                 \
-        if constexpr (DYH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.dY) + dbase_ + dtoff[it]);   \
+        if constexpr (DYH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const dx_h16*>(a.dY) + dbase_ + dtoff[it]);   \
         else v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.dY) + dbase_ + dtoff[it]);                  \
       }                                                                                                                       \
       dreg[it] = v;                                                                                                           \
@@ -1201,7 +1201,7 @@ __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel
     _Pragma("unroll") for (int it = 0; it < X_IT; ++it) {                                                                     \
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                                                    \
       if (xrow[it] >= xlo_ && xrow[it] < xhi_) {                                                                              \
-        if constexpr (XH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.X) + xbase_ + xtoff[it]);     \
+        if constexpr (XH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const dx_h16*>(a.X) + xbase_ + xtoff[it]);     \
         else v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.X) + xbase_ + xtoff[it]);                   \
       }                                                                                                                       \
       xreg[it] = v;                                                                                                           \
@@ -1247,12 +1247,12 @@ __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel
     while (c < total && !live()) advance();
     if (c < total) DX_WG_LOAD(b, nc);
     if (do_bias) {
-      const __bf16* col = Ds + (tid >> 6) * (WB_BK / (NT / 64)) * WB_LD + (tid & 63) * 2;
+      const dx_h16* col = Ds + (tid >> 6) * (WB_BK / (NT / 64)) * WB_LD + (tid & 63) * 2;
 #pragma unroll
       for (int k = 0; k < WB_BK / (NT / 64); ++k) {
         const unsigned v = *reinterpret_cast<const unsigned*>(col + k * WB_LD);
-        bsum0 += __builtin_bit_cast(float, v << 16);
-        bsum1 += __builtin_bit_cast(float, v & 0xffff0000u);
+        bsum0 += (float)__builtin_bit_cast(dx_h16, (unsigned short)(v & 0xffffu));
+        bsum1 += (float)__builtin_bit_cast(dx_h16, (unsigned short)(v >> 16));
       }
     }
 #pragma unroll
@@ -1268,7 +1268,7 @@ __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[i], xf[j], acc[t][i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) acc[t][i][j] = DX_MFMA_H16(df[i], xf[j], acc[t][i][j]);
       }
     }
   }
@@ -1398,8 +1398,8 @@ __global__ void pack_weights_batched_kernel(const PackDesc* __restrict__ descs) 
 // channels, k = output channels, taps flipped) read 8 output-channel rows at one input channel.
 __global__ __launch_bounds__(256) void pack_weights_batched_bf16_kernel(const PackDesc* __restrict__ descs) {
   const PackDesc d = descs[blockIdx.y];
-  __bf16* fwd = reinterpret_cast<__bf16*>(d.fwd);
-  __bf16* bwd = reinterpret_cast<__bf16*>(d.bwd);
+  dx_h16* fwd = reinterpret_cast<dx_h16*>(d.fwd);
+  dx_h16* bwd = reinterpret_cast<dx_h16*>(d.bwd);
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   const int fkb = d.CinP_f >> 5, nfb = (d.CoutP_f >> 4) * fkb;          // forward blocks per tap
   const int bkb = d.CoutP_b >> 5, nbb = bwd ? (d.CinP_b >> 4) * bkb : 0;
@@ -1418,7 +1418,7 @@ __global__ __launch_bounds__(256) void pack_weights_batched_bf16_kernel(const Pa
         if (t >= d.taps) break;
         bf16x8 h;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) h[e] = (__bf16)v[t][e];
+        for (int e = 0; e < 8; ++e) h[e] = (dx_h16)v[t][e];
         *reinterpret_cast<bf16x8*>(fwd + ((size_t)t * nfb + blk) * 512 + lane * 8) = h;
       }
     } else {
@@ -1436,7 +1436,7 @@ __global__ __launch_bounds__(256) void pack_weights_batched_bf16_kernel(const Pa
         if (t >= d.taps) break;
         bf16x8 h;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) h[e] = (__bf16)(d.taps == 3 ? v[2 - t][e] : v[0][e]);    // taps flipped
+        for (int e = 0; e < 8; ++e) h[e] = (dx_h16)(d.taps == 3 ? v[2 - t][e] : v[0][e]);    // taps flipped
         *reinterpret_cast<bf16x8*>(bwd + ((size_t)t * nbb + bb) * 512 + lane * 8) = h;
       }
     }
@@ -1526,7 +1526,7 @@ int dx_pack_weights(const float* W, void* fwd, void* bwd, int Cout, int Cin, int
   const int blocks = (int)std::min<size_t>((n + 255) / 256, 4096);
   hipStream_t s = (hipStream_t)stream;
   if (bf16)
-    hipLaunchKernelGGL(pack_weights_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, W, (__bf16*)fwd, (__bf16*)bwd, Cout, Cin, taps, d[0], d[1], d[2], d[3]);
+    hipLaunchKernelGGL(pack_weights_kernel<dx_h16>, dim3(blocks), dim3(256), 0, s, W, (dx_h16*)fwd, (dx_h16*)bwd, Cout, Cin, taps, d[0], d[1], d[2], d[3]);
   else
     hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, s, W, (float*)fwd, (float*)bwd, Cout, Cin, taps, d[0], d[1], d[2], d[3]);
   DX_LAUNCH_CHECK("dx_pack_weights");
@@ -1582,7 +1582,7 @@ int dx_conv_gemm(const void* Xv, int ldx, const void* Wp, const float* bias, voi
   } else if (bf16 && use_ws && d[1] == 128 && (long)B * dx_cdiv(N, 128) >= ws_min_tiles) {      // short-K layers: weight-stationary persistent kernel
     if (x_bf16) { if (taps == 3) launch_conv_ws<3, true>(a, s); else launch_conv_ws<1, true>(a, s); }
     else { if (taps == 3) launch_conv_ws<3, false>(a, s); else launch_conv_ws<1, false>(a, s); }
-  } else if (bf16) { if (taps == 3) launch_conv<__bf16, 3>(a, s); else launch_conv<__bf16, 1>(a, s); }
+  } else if (bf16) { if (taps == 3) launch_conv<dx_h16, 3>(a, s); else launch_conv<dx_h16, 1>(a, s); }
   else      { if (taps == 3) launch_conv<float, 3>(a, s);  else launch_conv<float, 1>(a, s); }
   dx_prof_end(DX_PROF_CONV_GEMM, s);
   DX_LAUNCH_CHECK("dx_conv_gemm");
@@ -1662,7 +1662,7 @@ int dx_colsum(const void* X, int ldx, float* out, long rows, int C, int x_bf16, 
   DX_REQUIRE(X && out && rows > 0 && C > 0 && ldx >= C, "dx_colsum: bad arguments");
   const int rpb = 256;
   dim3 grid(dx_cdiv(C, 256), (unsigned)((rows + rpb - 1) / rpb));
-  if (x_bf16) hipLaunchKernelGGL(colsum_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const __bf16*)X, ldx, out, rows, C, rpb);
+  if (x_bf16) hipLaunchKernelGGL(colsum_kernel<dx_h16>, grid, dim3(256), 0, (hipStream_t)stream, (const dx_h16*)X, ldx, out, rows, C, rpb);
   else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X, ldx, out, rows, C, rpb);
   DX_LAUNCH_CHECK("dx_colsum");
   return DX_OK;

@@ -27,6 +27,7 @@ struct AdamArgs {
   float* p; const float* g; float* m; float* v; long n;
   float lr, b1, b2, eps, wd, bc1, bc2_sqrt;
   const float* normsq; float max_norm;
+  float grad_scale;                 // gradients arrive multiplied by 1 / grad_scale (static loss scaling of the fp16 mode); 1 otherwise
 };
 
 __device__ __forceinline__ float adam_one(float& p, float g, float& m, float& v, const AdamArgs& a, float coef) {
@@ -39,8 +40,8 @@ __device__ __forceinline__ float adam_one(float& p, float g, float& m, float& v,
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
-  float coef = 1.f;
-  if (a.normsq && a.max_norm < INFINITY) coef = fminf(1.f, a.max_norm / (sqrtf(*a.normsq) + 1e-6f));  // clip_grad_norm_
+  float coef = a.grad_scale;
+  if (a.normsq && a.max_norm < INFINITY) coef *= fminf(1.f, a.max_norm / (sqrtf(*a.normsq) * a.grad_scale + 1e-6f));  // clip_grad_norm_
   const long n4 = a.n / 4;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     float4 p = reinterpret_cast<float4*>(a.p)[i], m = reinterpret_cast<float4*>(a.m)[i], v = reinterpret_cast<float4*>(a.v)[i];
@@ -67,13 +68,14 @@ int dx_sumsq(const float* x, long n, float* out, void* stream) {
 }
 
 // One Adam step on a flat bucket.  step >= 1.  normsq (optional, device scalar) = squared global gradient norm for clipping.
+// grad_scale: every gradient (and the norm) is multiplied by it first (1 / loss scale when the backward ran on a scaled loss).
 int dx_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
-                 float weight_decay, int step, const float* normsq, float max_norm, void* stream) {
+                 float weight_decay, int step, const float* normsq, float max_norm, float grad_scale, void* stream) {
   DX_REQUIRE(p && g && m && v && n > 0 && step >= 1, "dx_adam_step: bad arguments");
   DX_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
              "dx_adam_step: buffers must be 16-byte aligned");
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-  AdamArgs a{p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), normsq, max_norm};
+  AdamArgs a{p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), normsq, max_norm, grad_scale};
   const int blocks = (int)std::min<long>((n / 4 + 255) / 256 + 1, 4096);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   DX_LAUNCH_CHECK("dx_adam_step");

@@ -24,7 +24,7 @@ struct LnArgs {
   const int* lens;     // [B] or null (no mask)
   int halo;            // rows n >= lens[b] + halo are padding nobody reads: zero-filled, not computed (halo 0 = the reference's mask)
   float* y;            // [rows][C]
-  __bf16* y_h;         // optional bf16 copy of y (GEMM operand of the next layer: same rounding as its staging would apply)
+  dx_h16* y_h;         // optional bf16 copy of y (GEMM operand of the next layer: same rounding as its staging would apply)
   float* mean; float* rstd;            // [rows]
   int B, N;
   uint64_t seed_pre; uint32_t thresh_pre; float inv_keep_pre;     // dropout on `a` (thresh 0 = off)
@@ -61,7 +61,7 @@ __device__ __forceinline__ void row_store(float* p, int l, const float v[RowVec<
 }
 // bf16-stored rows: same lane -> column map, 8-byte accesses
 template <int C>
-__device__ __forceinline__ void row_load(const __bf16* p, int l, float v[RowVec<C>::E]) {
+__device__ __forceinline__ void row_load(const dx_h16* p, int l, float v[RowVec<C>::E]) {
 #pragma unroll
   for (int k = 0; k < RowVec<C>::K; ++k) {
     const bf16x4 t = *reinterpret_cast<const bf16x4*>(p + (k * RowVec<C>::LPR + l) * 4);
@@ -69,11 +69,11 @@ __device__ __forceinline__ void row_load(const __bf16* p, int l, float v[RowVec<
   }
 }
 template <int C>
-__device__ __forceinline__ void row_store(__bf16* p, int l, const float v[RowVec<C>::E]) {
+__device__ __forceinline__ void row_store(dx_h16* p, int l, const float v[RowVec<C>::E]) {
 #pragma unroll
   for (int k = 0; k < RowVec<C>::K; ++k) {
     bf16x4 t;
-    t[0] = (__bf16)v[k * 4]; t[1] = (__bf16)v[k * 4 + 1]; t[2] = (__bf16)v[k * 4 + 2]; t[3] = (__bf16)v[k * 4 + 3];
+    t[0] = (dx_h16)v[k * 4]; t[1] = (dx_h16)v[k * 4 + 1]; t[2] = (dx_h16)v[k * 4 + 2]; t[3] = (dx_h16)v[k * 4 + 3];
     *reinterpret_cast<bf16x4*>(p + (k * RowVec<C>::LPR + l) * 4) = t;
   }
 }
@@ -157,7 +157,7 @@ struct LnBwdArgs {
   const int* lens; int halo;
   float* dz;           // [rows][C] gradient w.r.t. z (== residual branch gradient)
   float* da;           // [rows][C] gradient w.r.t. the pre-dropout GEMM output, or null (then dz serves)
-  __bf16* dg_h;        // optional bf16 copy of the gradient that feeds the GEMM backward (da if present, else dz)
+  dx_h16* dg_h;        // optional bf16 copy of the gradient that feeds the GEMM backward (da if present, else dz)
   float* dw; float* dbias;             // [C] accumulated (atomics)
   float* dfilm; int ld_dfilm;          // [B][>=2C] accumulated, or null
   int B, N, rows_per_block;
@@ -562,14 +562,14 @@ int dx_ln_fwd(void* av, const void* resv, const float* w, const float* bias, con
   DX_REQUIRE(B > 0 && N > 0, "dx_ln_fwd: bad dims");
   DX_REQUIRE(p_pre >= 0.f && p_pre < 1.f && p_post >= 0.f && p_post < 1.f, "dx_ln_fwd: dropout p out of range");
   DX_REQUIRE(!film || ld_film >= 2 * C, "dx_ln_fwd: ld_film too small");
-  LnArgs k{a, res, w, bias, film, ld_film, lens, halo, y, (__bf16*)y_bf16_copy, mean, rstd, B, N,
+  LnArgs k{a, res, w, bias, film, ld_film, lens, halo, y, (dx_h16*)y_bf16_copy, mean, rstd, B, N,
            seed_pre, (uint32_t)lrintf(p_pre * 65536.f), 1.f / (1.f - p_pre),
            seed_post, (uint32_t)lrintf(p_post * 65536.f), 1.f / (1.f - p_post), seed_offset};
   hipStream_t s = (hipStream_t)stream;
   dx_prof_begin(DX_PROF_ROWS, s);
   const int grid = row_grid((long)B * N);
   if (C == 128) hipLaunchKernelGGL((ln_fwd_kernel<128, float>), dim3(dx_cdiv(grid, RowVec<128>::RPW)), dim3(256), 0, s, k);
-  else if (io_bf16) hipLaunchKernelGGL((ln_fwd_kernel<1024, __bf16>), dim3(grid), dim3(256), 0, s, k);
+  else if (io_bf16) hipLaunchKernelGGL((ln_fwd_kernel<1024, dx_h16>), dim3(grid), dim3(256), 0, s, k);
   else hipLaunchKernelGGL((ln_fwd_kernel<1024, float>), dim3(grid), dim3(256), 0, s, k);
   dx_prof_end(DX_PROF_ROWS, s);
   DX_LAUNCH_CHECK("dx_ln_fwd");
@@ -588,7 +588,7 @@ int dx_ln_bwd(const void* dyv, const void* zv, const float* mean, const float* r
   DX_REQUIRE(C == 128 || C == 1024, "dx_ln_bwd: C must be 128 or 1024 (got %d)", C);
   DX_REQUIRE((film == nullptr) == (dfilm == nullptr), "dx_ln_bwd: film and dfilm must come together");
   const int rpb = 64;
-  LnBwdArgs k{dy, z, mean, rstd, w, bias, film, ld_film, lens, halo, dz, da, (__bf16*)dg_bf16_copy, dw, dbias, dfilm, ld_dfilm, B, N, rpb, relu_mask,
+  LnBwdArgs k{dy, z, mean, rstd, w, bias, film, ld_film, lens, halo, dz, da, (dx_h16*)dg_bf16_copy, dw, dbias, dfilm, ld_dfilm, B, N, rpb, relu_mask,
               seed_pre, (uint32_t)lrintf(p_pre * 65536.f), 1.f / (1.f - p_pre),
               seed_post, (uint32_t)lrintf(p_post * 65536.f), 1.f / (1.f - p_post), seed_offset};
   hipStream_t s = (hipStream_t)stream;
@@ -598,7 +598,7 @@ int dx_ln_bwd(const void* dyv, const void* zv, const float* mean, const float* r
     if (film) hipLaunchKernelGGL((ln_bwd_kernel<CC, IO, true>), grid, dim3(256), 0, s, k); \
     else hipLaunchKernelGGL((ln_bwd_kernel<CC, IO, false>), grid, dim3(256), 0, s, k); } while (0)
   if (C == 128) DX_LN_BWD(128, float);
-  else if (io_bf16) DX_LN_BWD(1024, __bf16);
+  else if (io_bf16) DX_LN_BWD(1024, dx_h16);
   else DX_LN_BWD(1024, float);
 #undef DX_LN_BWD
   dx_prof_end(DX_PROF_ROWS, s);

@@ -158,16 +158,16 @@ class FFTBlockFn(torch.autograd.Function):
         att, lse = ops.attention_fwd(qkv, lens.i32, heads, s_attn, p_attn, prec=prec, seed_offset=so)
         z1 = ops.conv_gemm(att, packs['out'], out_b, lens=L, halo=0, prec=prec)
         sh = ops.gemm_shadow(prec)                 # bf16 mode: GEMM operands also exist as bf16 copies written by their producers
-        ln1 = ops.ln_fwd(z1, x, ln1_w, ln1_b, None, lens.i32, seed_pre=s_ln1, p_pre=p_attn, shadow=sh, seed_offset=so)
+        ln1 = ops.ln_fwd(z1, x, ln1_w, ln1_b, None, lens.i32, seed_pre=s_ln1, p_pre=p_attn, shadow=sh, seed_offset=so, prec=prec)
         y1, mean1, rstd1 = ln1[:3]
         y1g = ln1[3] if sh else y1                 # the copy the GEMMs read
         fused = ops.ff_pair_applies(y1g, packs['c1'], packs['c2'], prec)
         if fused:      # conv1 + ReLU + conv2 in ONE launch, the 1024-wide hidden tile consumed from LDS (h is still written: weight gradients)
-            z2, h = ops.ff_pair(y1g, packs['c1'], packs['c2'], c1_b, c2_b, L)
+            z2, h = ops.ff_pair(y1g, packs['c1'], packs['c2'], c1_b, c2_b, L, prec=prec)
         else:
             h = ops.conv_gemm(y1g, packs['c1'], c1_b, relu=True, lens=L, halo=1, out_dtype=hd, prec=prec)   # conv2 reads one row past the end
             z2 = ops.conv_gemm(h, packs['c2'], c2_b, lens=L, halo=0, prec=prec)
-        y2, mean2, rstd2 = ops.ln_fwd(z2, y1, ln2_w, ln2_b, film, lens.i32, seed_pre=s_ln2, p_pre=p_conv, seed_offset=so)
+        y2, mean2, rstd2 = ops.ln_fwd(z2, y1, ln2_w, ln2_b, film, lens.i32, seed_pre=s_ln2, p_pre=p_conv, seed_offset=so, prec=prec)
         ctx.save_for_backward(x, film, qkv, att, lse, z1, mean1, rstd1, y1g, h, z2, mean2, rstd2, ln1_w, ln1_b, ln2_w, ln2_b)
         ctx.lens, ctx.packs, ctx.heads = lens, packs, heads
         ctx.drop = (p_attn, p_conv, s_attn, s_ln1, s_ln2)
@@ -192,18 +192,18 @@ class FFTBlockFn(torch.autograd.Function):
         g = sk.get
         sh = ops.gemm_shadow(prec)
         so = ctx.seed_offset
-        r2 = ops.ln_bwd(dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, L, want_da=p_conv > 0, seed_pre=s_ln2, seed_offset=so,
+        r2 = ops.ln_bwd(dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, L, want_da=p_conv > 0, seed_pre=s_ln2, seed_offset=so, prec=prec,
                         p_pre=p_conv, arena=arena, w_sink=g('ln2_w'), b_sink=g('ln2_b'), shadow=sh)
         dz2, da2, dln2_w, dln2_b, dfilm = r2[:5]
         dff = r2[5] if sh else (da2 if da2 is not None else dz2)      # gradient w.r.t. the conv2 output, as the GEMMs read it
         dc2_w, dc2_b = ops.conv_wgrad(dff, h, packs['c2'], L, 0, arena=arena, w_sink=g('c2_w'), b_sink=g('c2_b'), prec=prec)
         if ctx.fused:  # conv2^T -> ReLU mask -> conv1^T in one launch, accumulated into the residual-branch gradient
-            dy1, dh = ops.ff_pair(dff, packs['c1'], packs['c2'], None, None, L, backward=True, aux=h, out=dz2, accumulate=True)
+            dy1, dh = ops.ff_pair(dff, packs['c1'], packs['c2'], None, None, L, backward=True, aux=h, out=dz2, accumulate=True, prec=prec)
         else:
             dh = ops.conv_gemm(dff, packs['c2'], None, transpose=True, relu_aux=h, lens=L, halo=1, out_dtype=h.dtype, prec=prec)
             dy1 = ops.conv_gemm(dh, packs['c1'], None, transpose=True, out=dz2, accumulate=True, lens=L, halo=0, prec=prec)  # + residual branch
         dc1_w, dc1_b = ops.conv_wgrad(dh, y1, packs['c1'], L, 1, arena=arena, w_sink=g('c1_w'), b_sink=g('c1_b'), prec=prec)
-        r1 = ops.ln_bwd(dy1, z1, mean1, rstd1, ln1_w, ln1_b, None, L, want_da=p_attn > 0, seed_pre=s_ln1, seed_offset=so,
+        r1 = ops.ln_bwd(dy1, z1, mean1, rstd1, ln1_w, ln1_b, None, L, want_da=p_attn > 0, seed_pre=s_ln1, seed_offset=so, prec=prec,
                         p_pre=p_attn, arena=arena, w_sink=g('ln1_w'), b_sink=g('ln1_b'), shadow=sh)
         dz1, da1, dln1_w, dln1_b = r1[:4]
         dproj = r1[5] if sh else (da1 if da1 is not None else dz1)
@@ -232,11 +232,11 @@ class AccentFrontFn(torch.autograd.Function):
         hd = ops.hidden_dtype(prec)                                           # 1024-wide tensors: bf16 in bf16 operand mode
         so = rt.seed_offset
         h0 = ops.conv_gemm(x0, packs['p0'], c0_b, relu=True, lens=L, halo=2, out_dtype=hd, prec=prec)   # three stacked k=3 convs: halos 2, 1, 0
-        y0, m0, r0 = ops.ln_fwd(h0, None, l0_w, l0_b, None, L, seed_post=seeds[0], p_post=p, halo=2, seed_offset=so)
+        y0, m0, r0 = ops.ln_fwd(h0, None, l0_w, l0_b, None, L, seed_post=seeds[0], p_post=p, halo=2, seed_offset=so, prec=prec)
         h1 = ops.conv_gemm(y0, packs['p1'], c1_b, relu=True, lens=L, halo=1, out_dtype=hd, prec=prec)
-        y1, m1, r1 = ops.ln_fwd(h1, None, l1_w, l1_b, None, L, seed_post=seeds[1], p_post=p, halo=1, seed_offset=so)
+        y1, m1, r1 = ops.ln_fwd(h1, None, l1_w, l1_b, None, L, seed_post=seeds[1], p_post=p, halo=1, seed_offset=so, prec=prec)
         h2 = ops.conv_gemm(y1, packs['p2'], c2_b, relu=True, lens=L, halo=0, prec=prec)
-        y2, m2, r2 = ops.ln_fwd(h2, None, l2_w, l2_b, None, L, seed_post=seeds[2], p_post=p, halo=0, seed_offset=so)
+        y2, m2, r2 = ops.ln_fwd(h2, None, l2_w, l2_b, None, L, seed_post=seeds[2], p_post=p, halo=0, seed_offset=so, prec=prec)
         energy, pitch = energy.contiguous(), pitch.contiguous()
         out = ops.accent_sum(y2, energy, pitch, we, be, wp, bp, pe, lens.i32)
         ctx.save_for_backward(x0, h0, m0, r0, y0, h1, m1, r1, y1, h2, m2, r2, energy, pitch, l0_w, l0_b, l1_w, l1_b, l2_w, l2_b)
@@ -258,15 +258,15 @@ class AccentFrontFn(torch.autograd.Function):
         prec = ctx.prec
         sk = {k: _sink(v, ctx.sink) for k, v in P.items()}
         g = sk.get
-        dz2, _, dl2_w, dl2_b, _ = ops.ln_bwd(dout, h2, m2, r2, l2_w, l2_b, None, L, relu_mask=True, seed_post=seeds[2], p_post=p, seed_offset=so,
+        dz2, _, dl2_w, dl2_b, _ = ops.ln_bwd(dout, h2, m2, r2, l2_w, l2_b, None, L, relu_mask=True, seed_post=seeds[2], p_post=p, seed_offset=so, prec=prec,
                                               w_sink=g('l2_w'), b_sink=g('l2_b'), halo=0, arena=arena)
         dc2_w, dc2_b = ops.conv_wgrad(dz2, y1, packs['p2'], L, 0, w_sink=g('c2_w'), b_sink=g('c2_b'), prec=prec, arena=arena)
         dy1 = ops.conv_gemm(dz2, packs['p2'], None, transpose=True, lens=L, halo=1, out_dtype=h1.dtype, prec=prec)
-        dz1, _, dl1_w, dl1_b, _ = ops.ln_bwd(dy1, h1, m1, r1, l1_w, l1_b, None, L, relu_mask=True, seed_post=seeds[1], p_post=p, seed_offset=so,
+        dz1, _, dl1_w, dl1_b, _ = ops.ln_bwd(dy1, h1, m1, r1, l1_w, l1_b, None, L, relu_mask=True, seed_post=seeds[1], p_post=p, seed_offset=so, prec=prec,
                                               w_sink=g('l1_w'), b_sink=g('l1_b'), halo=1, arena=arena)
         dc1_w, dc1_b = ops.conv_wgrad(dz1, y0, packs['p1'], L, 1, w_sink=g('c1_w'), b_sink=g('c1_b'), prec=prec, arena=arena)
         dy0 = ops.conv_gemm(dz1, packs['p1'], None, transpose=True, lens=L, halo=2, out_dtype=h0.dtype, prec=prec)
-        dz0, _, dl0_w, dl0_b, _ = ops.ln_bwd(dy0, h0, m0, r0, l0_w, l0_b, None, L, relu_mask=True, seed_post=seeds[0], p_post=p, seed_offset=so,
+        dz0, _, dl0_w, dl0_b, _ = ops.ln_bwd(dy0, h0, m0, r0, l0_w, l0_b, None, L, relu_mask=True, seed_post=seeds[0], p_post=p, seed_offset=so, prec=prec,
                                               w_sink=g('l0_w'), b_sink=g('l0_b'), halo=2, arena=arena)
         dc0_w, dc0_b = ops.conv_wgrad(dz0, x0, packs['p0'], L, 2, w_sink=g('c0_w'), b_sink=g('c0_b'), prec=prec, arena=arena)
         return (None, None, None, None, None, None, None, None,

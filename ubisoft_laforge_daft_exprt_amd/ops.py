@@ -12,7 +12,7 @@ import torch
 
 from ._lib import lib
 
-PRECISIONS = ('f32', 'bf16')
+PRECISIONS = ('f32', 'bf16', 'fp16')
 
 
 class Runtime:
@@ -63,7 +63,7 @@ DEFAULT = Runtime('f32')
 
 
 def set_precision(name: str) -> None:
-    """'f32': exact-f32 MFMA operands (parity mode).  'bf16': bf16 MFMA operands, fp32 accumulate (throughput mode).
+    """'f32': exact-f32 MFMA operands (parity mode).  'bf16' / 'fp16': 16-bit MFMA operands, fp32 accumulate (throughput modes).
     Sets the default for models / losses constructed afterwards (and for kernel-level calls without a model); a live model is
     switched with ``model.set_precision(name)``."""
     DEFAULT.set_precision(name)
@@ -82,8 +82,16 @@ def record_launches(enable: bool, rt=None):
 
 
 def _half(prec) -> int:
-    """operand-mode flag of the C ABI: 0 = exact f32, 1 = bf16 operands"""
-    return 1 if prec == 'bf16' else 0
+    """operand-mode flag of the C ABI: 0 = exact f32, 1 = 16-bit operands (bf16 build, or fp16 in the ``_f16`` twins)"""
+    return 1 if prec in ('bf16', 'fp16') else 0
+
+
+_H16 = {'bf16': torch.bfloat16, 'fp16': torch.float16}
+
+
+def _fn(name, prec):
+    """The C entry point serving operand precision ``prec``: the ``_f16`` twin in fp16 mode (include/daft_exprt_hip.h)."""
+    return getattr(lib(), name + '_f16' if prec == 'fp16' else name)
 
 
 def _p(t):
@@ -95,18 +103,26 @@ def _stream():
 
 
 def _chk(t, name):
-    if not t.is_cuda or t.dtype not in (torch.float32, torch.bfloat16):
-        raise TypeError(f'{name} must be a float32 (or, in bf16 mode, bfloat16) tensor on the GPU (got {t.dtype} on {t.device})')
+    if not t.is_cuda or t.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        raise TypeError(f'{name} must be a float32 (or, in a 16-bit operand mode, bfloat16 / float16) tensor on the GPU (got {t.dtype} on {t.device})')
     return t
 
 
 def _is_bf16(t):
-    return int(t is not None and t.dtype == torch.bfloat16)
+    """1 when the tensor is stored in the 16-bit type of its operand mode (the C ABI's ``*_bf16`` storage flags)"""
+    return int(t is not None and t.dtype in (torch.bfloat16, torch.float16))
+
+
+def _check_h16(prec, *tensors):
+    want = _H16.get(prec)
+    for t in tensors:
+        if t is not None and t.dtype in (torch.bfloat16, torch.float16) and t.dtype != want:
+            raise TypeError(f'{t.dtype} tensor in {prec!r} operand mode')
 
 
 def hidden_dtype(prec=None):
     """Storage type of the 1024-wide hidden activations: bf16 in bf16 operand mode (their HBM traffic bounds the step)."""
-    return torch.bfloat16 if _half(prec or DEFAULT.precision) else torch.float32
+    return _H16.get(prec or DEFAULT.precision, torch.float32)
 
 
 def _rows(t):
@@ -144,7 +160,7 @@ def repack_all(rt=None, packs=None) -> int:
         if len(rt._tables) > 8:
             rt._tables.clear()
         rt._tables[sig] = table
-    lib().dx_pack_weights_batched(_p(table), len(stale), _half(prec), _stream())
+    _fn('dx_pack_weights_batched', prec)(_p(table), len(stale), _half(prec), _stream())
     for pk, img in stale:
         img.key = pk._current_key()
     return len(stale)
@@ -192,7 +208,7 @@ class PackedWeight:
         if img is None or img.fwd.device != w.device:
             img = _PackImage()
             img.half = _half(prec)
-            dt = torch.bfloat16 if img.half else torch.float32
+            dt = _H16.get(prec, torch.float32)
             dims = (ctypes.c_int * 4)()
             lib().dx_pack_dims(self.cout, self.cin, img.half, ctypes.cast(dims, ctypes.c_void_p))
             img.dims = [int(d) for d in dims]
@@ -207,7 +223,7 @@ class PackedWeight:
         img = self._image(prec)
         key = self._current_key()
         if key != img.key:                     # (the padded speaker-logit layer's copy bumps its _version under capture: recorded too)
-            lib().dx_pack_weights(_p(self.weight.detach()), _p(img.fwd), _p(img.bwd), self.cout, self.cin, self.taps, img.half, _stream())
+            _fn('dx_pack_weights', prec)(_p(self.weight.detach()), _p(img.fwd), _p(img.bwd), self.cout, self.cin, self.taps, img.half, _stream())
             img.key = key
         return img
 
@@ -228,6 +244,8 @@ def conv_gemm(x, pack: PackedWeight, bias=None, *, transpose=False, relu=False, 
     """y = epilogue(conv(x)).  ``transpose=True`` runs the input-gradient convolution (x is dY, result is dX).
     ``prec``: operand precision (default: the pack's runtime); backward passes hand in the precision their forward captured."""
     _chk(x, 'x')
+    prec = prec or pack.rt.precision
+    _check_h16(prec, x, out, relu_aux)
     img = pack.image(prec)
     if x.dim() == 2:
         B_, N_ = (1, x.shape[0]) if B is None else (B, N)
@@ -241,7 +259,7 @@ def conv_gemm(x, pack: PackedWeight, bias=None, *, transpose=False, relu=False, 
         out = torch.empty(*x.shape[:-1], cout, dtype=out_dtype, device=x.device)
     ldy = _rows(out)
     _log(pack, ('conv', B_ * N_, N_, cin, cout, pack.taps))
-    lib().dx_conv_gemm(_p(x), ldx, _p(img.bwd if transpose else img.fwd), _p(bias), _p(out), ldy, B_, N_, cin, cout, pack.taps,
+    _fn('dx_conv_gemm', prec)(_p(x), ldx, _p(img.bwd if transpose else img.fwd), _p(bias), _p(out), ldy, B_, N_, cin, cout, pack.taps,
                        img.half, int(relu), _p(post_scale), _p(post_shift), _p(relu_aux),
                        0 if relu_aux is None else _rows(relu_aux), int(accumulate), _p(lens), int(mask_rows), float(out_scale), int(halo),
                        _is_bf16(x), _is_bf16(out), _is_bf16(relu_aux), _stream())
@@ -255,30 +273,31 @@ def ff_pair_applies(x, pack1: PackedWeight, pack2: PackedWeight, prec) -> bool:
     """The fused feed-forward kernel serves bf16 operand mode at the reference shape (128 -> F -> 128, k = 3) when the launch has
     enough 126-token tiles to occupy the chip: one workgroup per tile runs ~40 us whatever the grid, so the short symbol-level
     batches (48 tiles at C2: measured 40 vs 37 us forward, 55 vs 42 us backward) stay on the two-launch path."""
-    return (prec == 'bf16' and x.dtype == torch.bfloat16 and x.dim() == 3 and x.shape[2] == 128 and pack1.taps == 3 and pack2.taps == 3
+    return (prec in _H16 and x.dtype == _H16[prec] and x.dim() == 3 and x.shape[2] == 128 and pack1.taps == 3 and pack2.taps == 3
             and pack1.cin == 128 and pack2.cout == 128 and pack2.cin == pack1.cout and pack1.cout % 128 == 0
             and x.shape[0] * ((x.shape[1] + 125) // 126) >= _FF_FUSED_MIN_TILES)
 
 
 def ff_pair(x, pack1: PackedWeight, pack2: PackedWeight, bias1, bias2, lens, *, backward=False, aux=None, out=None, accumulate=False,
-            halo=1):
+            halo=1, prec=None):
     """The conv feed-forward pair in ONE launch (bf16 operand mode; csrc/dx_ffpair.hip).
     forward : (z, h)  with h = relu(conv1(x) + b1) [bf16, kept for the weight gradients], z = conv2(h) + b2 [fp32]
     backward: (dx, dh) with x = d(loss)/dz as bf16, dh = conv2^T(x) masked by ``aux`` = h > 0 [bf16], dx (+)= conv1^T(dh)
     ``pack1`` / ``pack2`` are the packs of conv1 (F, 128, 3) and conv2 (128, F, 3) in both directions."""
-    if x.dtype != torch.bfloat16:
-        raise TypeError('ff_pair runs in bf16 operand mode on a bf16 activation tensor')
+    prec = pack1.rt.precision if prec is None else prec
+    if prec not in _H16 or x.dtype != _H16[prec]:
+        raise TypeError('ff_pair runs in a 16-bit operand mode on an activation tensor of that type')
     B, N, D = x.shape
     Fc = pack1.cout
     if D != 128 or pack1.cin != 128 or pack2.cout != 128 or pack2.cin != Fc or pack1.taps != 3 or pack2.taps != 3:
         raise ValueError('ff_pair is built for conv(k=3, 128 -> F) -> conv(k=3, F -> 128)')
-    i1, i2 = pack1.image('bf16'), pack2.image('bf16')
+    i1, i2 = pack1.image(prec), pack2.image(prec)
     wa, wb = (i2.bwd, i1.bwd) if backward else (i1.fwd, i2.fwd)
-    h = torch.empty(B, N, Fc, dtype=torch.bfloat16, device=x.device)
+    h = torch.empty(B, N, Fc, dtype=_H16[prec], device=x.device)
     if out is None:
         out = torch.empty(B, N, 128, dtype=torch.float32, device=x.device)
     _log(pack1, ('ffpair', B * N, N, 128, Fc, 3))
-    lib().dx_ff_pair(_p(x), _rows(x), _p(wa), _p(wb), _p(bias1), _p(bias2), _p(aux), 0 if aux is None else _rows(aux), _p(h), _rows(h),
+    _fn('dx_ff_pair', prec)(_p(x), _rows(x), _p(wa), _p(wb), _p(bias1), _p(bias2), _p(aux), 0 if aux is None else _rows(aux), _p(h), _rows(h),
                      _p(out), _rows(out), B, N, Fc, int(not backward), int(accumulate), _p(lens), int(halo), _stream())
     return out, h
 
@@ -336,8 +355,10 @@ def conv_wgrad(dy, x, pack: PackedWeight, lens=None, halo=-1, bias=True, arena=N
     g = w_sink if w_sink is not None else _zeros(arena, *pack.weight.shape, device=x.device)
     db = b_sink if b_sink is not None else (_zeros(arena, pack.cout, device=x.device) if bias else None)
     _log(pack, ('wgrad', B_ * N_, N_, pack.cin, pack.cout, pack.taps))
-    lib().dx_conv_wgrad(_p(dy), _rows(dy), _p(x), _rows(x), _p(g), B_, N_, pack.cin, pack.cout, pack.taps, _p(lens), int(halo),
-                        _half(prec or pack.rt.precision), _is_bf16(dy), _is_bf16(x), _p(db), _stream())
+    prec = prec or pack.rt.precision
+    _check_h16(prec, dy, x)
+    _fn('dx_conv_wgrad', prec)(_p(dy), _rows(dy), _p(x), _rows(x), _p(g), B_, N_, pack.cin, pack.cout, pack.taps, _p(lens), int(halo),
+                               _half(prec), _is_bf16(dy), _is_bf16(x), _p(db), _stream())
     return (None if w_sink is not None else g), (None if b_sink is not None else db)
 
 
@@ -354,8 +375,9 @@ def attention_fwd(qkv, lens, heads, seed, p_drop, prec=None, seed_offset=None):
     D = D3 // 3
     ctx = torch.empty(B, N, D, dtype=torch.float32, device=qkv.device)
     lse = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device)
-    lib().dx_attention_fwd(_p(qkv), _rows(qkv), _p(lens), _p(ctx), D, _p(lse), B, N, heads, D, seed, _p(seed_offset), float(p_drop),
-                           _half(prec or DEFAULT.precision), _is_bf16(qkv), _stream())
+    prec = prec or DEFAULT.precision
+    _fn('dx_attention_fwd', prec)(_p(qkv), _rows(qkv), _p(lens), _p(ctx), D, _p(lse), B, N, heads, D, seed, _p(seed_offset), float(p_drop),
+                           _half(prec), _is_bf16(qkv), _stream())
     return ctx, lse
 
 
@@ -364,8 +386,9 @@ def attention_bwd(qkv, ctx, dctx, lse, lens, heads, seed, p_drop, out_dtype=torc
     D = D3 // 3
     dqkv = torch.empty(B, N, D3, dtype=out_dtype, device=qkv.device)
     delta = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device)
-    lib().dx_attention_bwd(_p(qkv), _rows(qkv), _p(ctx), _p(dctx), _rows(dctx), _p(lse), _p(delta), _p(lens), _p(dqkv), _rows(dqkv),
-                           B, N, heads, D, seed, _p(seed_offset), float(p_drop), _half(prec or DEFAULT.precision), _is_bf16(qkv), _is_bf16(dqkv),
+    prec = prec or DEFAULT.precision
+    _fn('dx_attention_bwd', prec)(_p(qkv), _rows(qkv), _p(ctx), _p(dctx), _rows(dctx), _p(lse), _p(delta), _p(lens), _p(dqkv), _rows(dqkv),
+                           B, N, heads, D, seed, _p(seed_offset), float(p_drop), _half(prec), _is_bf16(qkv), _is_bf16(dqkv),
                            _stream())
     return dqkv
 
@@ -375,29 +398,31 @@ def gemm_shadow(prec=None):
     return bool(_half(prec or DEFAULT.precision))
 
 
-def ln_fwd(a, res, w, b, film, lens, *, seed_pre=0, p_pre=0.0, seed_post=0, p_post=0.0, halo=0, shadow=False, seed_offset=None):
+def ln_fwd(a, res, w, b, film, lens, *, seed_pre=0, p_pre=0.0, seed_post=0, p_post=0.0, halo=0, shadow=False, seed_offset=None, prec=None):
     """In place on ``a`` (becomes z = drop(a) + res).  Returns (y, mean, rstd) or, with ``shadow``, (y, mean, rstd, y_bf16)."""
     B, N, C = a.shape
     y = torch.empty_like(a)
-    y_h = torch.empty(B, N, C, dtype=torch.bfloat16, device=a.device) if shadow else None
+    prec = prec or DEFAULT.precision
+    y_h = torch.empty(B, N, C, dtype=_H16[prec], device=a.device) if shadow else None
     mean = torch.empty(B, N, dtype=torch.float32, device=a.device)
     rstd = torch.empty(B, N, dtype=torch.float32, device=a.device)
-    lib().dx_ln_fwd(_p(a), _p(res), _p(w), _p(b), _p(film), 0 if film is None else film.stride(0), _p(lens), int(halo), _p(y), _p(mean), _p(rstd),
+    _fn('dx_ln_fwd', prec)(_p(a), _p(res), _p(w), _p(b), _p(film), 0 if film is None else film.stride(0), _p(lens), int(halo), _p(y), _p(mean), _p(rstd),
                     B, N, C, seed_pre, float(p_pre), seed_post, float(p_post), _p(seed_offset), _is_bf16(a), _p(y_h), _stream())
     return (y, mean, rstd, y_h) if shadow else (y, mean, rstd)
 
 
 def ln_bwd(dy, z, mean, rstd, w, b, film, lens, *, relu_mask=False, want_da=False, seed_pre=0, p_pre=0.0, seed_post=0, p_post=0.0,
-           arena=None, w_sink=None, b_sink=None, halo=0, shadow=False, seed_offset=None):
+           arena=None, w_sink=None, b_sink=None, halo=0, shadow=False, seed_offset=None, prec=None):
     """Returns (dz, da or None, dw, db, dfilm or None[, dg_bf16]); dw/db are None when accumulated straight into the given sinks."""
     B, N, C = z.shape
     dz = torch.empty_like(z)
-    dg_h = torch.empty(B, N, C, dtype=torch.bfloat16, device=z.device) if shadow else None
+    prec = prec or DEFAULT.precision
+    dg_h = torch.empty(B, N, C, dtype=_H16[prec], device=z.device) if shadow else None
     da = torch.empty_like(z) if (want_da and not shadow) else None      # with a bf16 shadow the GEMMs read that copy instead
     dw = w_sink if w_sink is not None else _zeros(arena, C, device=z.device)
     db = b_sink if b_sink is not None else _zeros(arena, C, device=z.device)
     dfilm = _zeros(arena, B, 2 * C, device=z.device) if film is not None else None
-    lib().dx_ln_bwd(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(film), 0 if film is None else film.stride(0), _p(lens), int(halo),
+    _fn('dx_ln_bwd', prec)(_p(dy), _p(z), _p(mean), _p(rstd), _p(w), _p(b), _p(film), 0 if film is None else film.stride(0), _p(lens), int(halo),
                     _p(dz), _p(da), _p(dw), _p(db), _p(dfilm), 2 * C, B, N, C, int(relu_mask),
                     seed_pre, float(p_pre), seed_post, float(p_post), _p(seed_offset), _is_bf16(z), _p(dg_h), _stream())
     out = (dz, da, (None if w_sink is not None else dw), (None if b_sink is not None else db), dfilm)

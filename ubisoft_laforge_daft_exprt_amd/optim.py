@@ -56,8 +56,9 @@ class FusedAdam:
         return [{'lr': self.lr, 'betas': self.betas, 'eps': self.eps, 'weight_decay': self.weight_decay, 'amsgrad': False,
                  'params': list(range(len(self.params)))}]
 
-    def step(self, lr=None):
-        """Call after ``reducer.finish()``.  Returns the global gradient norm (device scalar, no host sync)."""
+    def step(self, lr=None, grad_scale=1.0):
+        """Call after ``reducer.finish()``.  Returns the global gradient norm (device scalar, no host sync).
+        ``grad_scale``: the gradients in the buckets are multiplied by it on the fly (1 / loss scale in fp16 mode)."""
         if lr is not None:
             self.lr = lr
         self.step_count += 1
@@ -66,10 +67,10 @@ class FusedAdam:
             lib().dx_sumsq(_p(g), g.numel(), _p(self.normsq), _stream())
         for p, g, m, v in zip(self.pflat, self.reducer.flat, self.m, self.v):
             lib().dx_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(self.lr), self.betas[0], self.betas[1], float(self.eps),
-                               float(self.weight_decay), self.step_count, _p(self.normsq), float(self.max_norm), _stream())
+                               float(self.weight_decay), self.step_count, _p(self.normsq), float(self.max_norm), float(grad_scale), _stream())
         self.runtime.invalidate_packs()             # parameters were written behind autograd's back: force a re-pack ...
         ops.repack_all(self.runtime)                # ... which is one launch for the whole model
-        return self.normsq.sqrt()
+        return self.normsq.sqrt() * grad_scale if grad_scale != 1.0 else self.normsq.sqrt()
 
     # -- checkpoint layout of torch.optim.Adam -------------------------------------------------------------------------
     def state_dict(self):

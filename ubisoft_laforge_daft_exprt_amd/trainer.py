@@ -55,6 +55,9 @@ class Trainer:
         self.device = next(model.parameters()).device
         self.reducer = GradientReducer(model, bucket_mb=bucket_mb, process_group=process_group, grad_sink=grad_sink, group_of=_group_of)
         self.use_graphs, self.max_graphs = bool(use_graphs), int(max_graphs)
+        # fp16 operand mode: gradients that live in 16-bit tensors (dqkv, the 1024-wide hidden gradients) would underflow; the
+        # backward runs on loss * loss_scale and the fused Adam multiplies by 1 / loss_scale (static scale; bf16 needs none)
+        self._fp16_loss_scale = float(getattr(hparams, 'loss_scale', 4096.0))
         self.graphs = {}
         self.adv_weight = torch.zeros((), dtype=torch.float32, device=self.device)    # read by the captured loss
         if model.runtime.seed_offset is None:
@@ -67,6 +70,10 @@ class Trainer:
         self.nan_steps = 0
         self.best_val_loss = float('inf')
         model.train()
+
+    @property
+    def loss_scale(self):
+        return self._fp16_loss_scale if self.model.runtime.precision == 'fp16' else 1.0
 
     # -- device work of one update ----------------------------------------------------------------------------------------
     def _forward_loss(self, inputs, targets, iteration):
@@ -90,10 +97,10 @@ class Trainer:
         tot, terms = None, []
         for inputs, targets in parsed:
             loss, indiv = self._forward_loss(inputs, targets, iteration)
-            loss = loss / k
             with red.accumulate(sync=False):                 # the exchange is launched explicitly, group by group
-                loss.backward()
-            tot = loss.detach() if tot is None else tot + loss.detach()
+                (loss * (self.loss_scale / k)).backward()
+            part = loss.detach() / k if k != 1 else loss.detach()
+            tot = part if tot is None else tot + part
             terms.append(indiv)
         cuts, model.backward_split = model.backward_split, None
         launch(0)
@@ -109,7 +116,7 @@ class Trainer:
 
     def _parse(self, batches):
         parsed = [self.model.parse_batch(self.device, b) for b in batches]
-        key = tuple((tuple(i[0].shape), tuple(i[8].shape)) for i, _ in parsed)     # (B, L_max), (B, n_mel, T_max) per micro-batch
+        key = (self.model.runtime.precision,) + tuple((tuple(i[0].shape), tuple(i[8].shape)) for i, _ in parsed)   # (B, L_max), (B, n_mel, T_max) per micro-batch
         return parsed, key
 
     def _capture(self, parsed, key):
@@ -185,7 +192,7 @@ class Trainer:
             tot, terms, phase_b = self._phases(parsed, self.iteration, red.launch_group)
             phase_b()
         red.finish()
-        grad_norm = self.optimizer.step(lr=self.learning_rate)
+        grad_norm = self.optimizer.step(lr=self.learning_rate, grad_scale=1.0 / self.loss_scale)
         self.iteration += 1
         self.learning_rate = update_learning_rate(self.hparams, self.iteration)
         return tot, terms, grad_norm
