@@ -555,7 +555,7 @@ def test_ff_pair_fused_matches_two_launches_and_torch(ops, precision, B, N, lens
     and against fp32 PyTorch on the same bf16-rounded operands: forward pair and input-gradient pair, lengths on both sides of
     the 126-token tile edges."""
     D, Fc = 128, 1024
-    H16 = H16 if precision == 'bf16' else torch.float16
+    H16 = torch.bfloat16 if precision == "bf16" else torch.float16
     ops.set_precision(precision)
     try:
         w1 = randn(Fc, D, 3, seed=1, scale=1.0 / math.sqrt(3 * D))
