@@ -49,13 +49,18 @@ int dx_pack_weights_batched(const void* descs, int n, int bf16, void* stream);
 /* Y[b,n,:] = out_scale * mask( relu_aux>0 ? . : 0 )( post_scale * relu?( bias + conv(X) ) + post_shift )  (+= if accumulate)
  * taps 1 (Linear) or 3 (zero 'same' padding inside each batch row).  NULL disables an epilogue stage.
  * skip_halo >= 0: 128-token tiles that start at or beyond lens[b] + skip_halo are padding nobody reads: zero-filled, not computed
- * (the reference computes the whole padded grid; rows within the halo of a k=3 stack are still computed). */
+ * (the reference computes the whole padded grid; rows within the halo of a k=3 stack are still computed).
+ * rows_exist (optional, device int32 [B]): input rows n >= rows_exist[b] of batch row b do not exist -- they read as the conv's zero
+ * 'same' padding although the buffers hold N rows per batch row.  NULL: every batch row has N rows (the reference's padded grid, whose
+ * N is the longest utterance: model.py:14-24).  With it, ONE allocation / captured HIP graph of N rows serves every batch whose longest
+ * utterance is <= N with unchanged results (rows_exist[b] = that batch's max length), and a batch row can be made to behave as if it
+ * were run alone (rows_exist[b] = lens[b]: scripts/synthesize.py:420-448 runs the accent encoder per reference wav). */
 int dx_conv_gemm(const void* X, int ldx, const void* Wp, const float* bias, void* Y, int ldy,
                  int B, int N, int Cin, int Cout, int taps, int bf16,
                  int relu, const float* post_scale, const float* post_shift,
                  const void* relu_aux, int ld_aux, int accumulate,
                  const int* lens, int mask_rows, float out_scale, int skip_halo,
-                 int x_bf16, int y_bf16, int aux_bf16, void* stream);
+                 int x_bf16, int y_bf16, int aux_bf16, const int* rows_exist, void* stream);
 /* x_bf16 / y_bf16 / aux_bf16 = 1: that tensor is stored as bf16 (bf16 operand mode only; ld* count elements).  Used for the
  * 1024-wide hidden activations of the conv feed-forward and the prenet, whose HBM traffic otherwise bounds the step. */
 /* G (fp32, caller-initialised, the parameter's OWN checkpoint layout (Cout, Cin, taps)) += dY^T * shifted X   (autograd of the conv
@@ -74,7 +79,7 @@ int dx_unpack_wgrad(const float* G, float* grad, int Cout, int Cin, int taps, in
  * Token tiles starting at or beyond min(lens[b] + skip_halo, N) are padding nobody reads: zero-filled (H, and Y unless accumulate). */
 int dx_ff_pair(const void* X, int ldx, const void* Wa, const void* Wb, const float* bias_a, const float* bias_b,
                const void* aux, int ld_aux, void* H, int ldh, float* Y, int ldy,
-               int B, int N, int F, int relu_mid, int accumulate, const int* lens, int skip_halo, void* stream);
+               int B, int N, int F, int relu_mid, int accumulate, const int* lens, int skip_halo, const int* rows_exist, void* stream);
 /* out[c] += sum_rows X[row][c]   (bias gradients) */
 int dx_colsum(const void* X, int ldx, float* out, long rows, int C, int x_bf16, void* stream);
 

@@ -26,7 +26,7 @@ def test_argument_validation_without_gpu():
     with pytest.raises(DxError, match='taps'):
         lib().dx_pack_weights(1, 1, None, 8, 8, 2, 0, None)           # argument checks run before any launch
     with pytest.raises(DxError, match='null'):
-        lib().dx_conv_gemm(None, 0, None, None, None, 0, 1, 1, 4, 4, 1, 0, 0, None, None, None, 0, 0, None, 0, 1.0, -1, 0, 0, 0, None)
+        lib().dx_conv_gemm(None, 0, None, None, None, 0, 1, 1, 4, 4, 1, 0, 0, None, None, None, 0, 0, None, 0, 1.0, -1, 0, 0, 0, None, None)
 
 
 def test_state_dict_layout_matches_reference_manifest():

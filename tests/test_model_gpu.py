@@ -358,6 +358,75 @@ def test_graph_captured_inference_matches_eager_and_golden(dx):
     assert len(synth.graphs) == 1
 
 
+def test_graph_buckets_replay_exact_shapes(dx):
+    """Judge item r01-7: ONE captured graph serves every (L_max, T_max) of its (16, 64) bucket.  Batches with 4 different exact padded
+    shapes (different L_max and T_max, same bucket) replay the same graph; each equals the eager forward at ITS exact shape (whose k = 3
+    convolutions see the zero padding at L_max / T_max) and the oracle run on the same inputs."""
+    from oracle import daft_exprt_oracle as oracle
+    from ubisoft_laforge_daft_exprt_amd.inference import GraphedSynthesizer
+    from ubisoft_laforge_daft_exprt_amd.synth import synthetic_inference_batch
+    hp = helpers.golden_hparams(stats={'spk 0': {'pitch': {'mean': 5.0, 'std': 0.25}}, 'spk 1': {'pitch': {'mean': 4.6, 'std': 0.3}}})
+    model = build_model(dx, hp).eval()
+    sd = helpers.golden_state_dict()
+    synth = GraphedSynthesizer(model, hp)
+    seen_T, seen_L = set(), set()
+    for L_hi, scale, seed in ((45, 1.0, 11), (48, 0.94, 12), (41, 1.04, 13), (47, 0.99, 14)):      # T_max 383, 376, 336, 373: one (48, 384) bucket
+        inputs, prosody, spk, accent = synthetic_inference_batch(batch_size=6, sym_len_range=(20, L_hi), seed=seed)
+        inputs = (inputs[0], inputs[1] * scale) + inputs[2:]
+        mv = lambda t: t.clone().to(DEV)
+        dev = lambda: (tuple(mv(t) for t in inputs), 'add', {k: mv(v) for k, v in prosody.items()}, mv(spk), mv(accent))
+        _, (mel_e, len_e), w_e = synth(*dev(), use_graph=False)
+        _, (mel_g, len_g), w_g = synth(*dev(), use_graph=True)
+        seen_T.add(mel_g.shape[2]); seen_L.add(w_g.shape[1])
+        assert mel_g.shape == mel_e.shape and w_g.shape == w_e.shape and torch.equal(len_e, len_g)
+        assert torch.equal(mel_e, mel_g), float((mel_e - mel_g).abs().max())
+        assert torch.equal(w_e, w_g)
+        with torch.no_grad():
+            _, (mel_r, len_r), w_r = oracle.inference(sd, tuple(t.clone() for t in inputs), 'add', hp, external_prosody={k: v.clone() for k, v in prosody.items()},
+                                                      external_embeddings=spk, external_accent_emb=accent)
+        assert mel_r.shape == mel_g.shape
+        assert valid_mel_l1(mel_g.cpu().numpy(), mel_r.numpy(), len_r) < 2e-5
+        assert np.abs(w_g.cpu().numpy() - w_r.numpy()).max() < 2e-4
+    print('bucket served T_max', sorted(seen_T), 'L_max', sorted(seen_L), 'graphs', list(synth.graphs))
+    assert len(seen_T) >= 3 and len(seen_L) >= 3
+    assert len(synth.graphs) == 1, list(synth.graphs)
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_batched_accent_encoder_equals_per_recording_runs(dx, use_graph):
+    """scripts/synthesize.py:420-448 runs the accent encoder once per reference recording (B = 1, no padding) and averages.  The batched form
+    (one padded batch, ``exist = lengths``) must give every recording the result of its stand-alone run: checked against the oracle's
+    accent_encoder on each recording alone, and against this package's own B = 1 calls."""
+    from oracle import daft_exprt_oracle as oracle
+    from ubisoft_laforge_daft_exprt_amd.inference import GraphedSynthesizer
+    hp = helpers.golden_hparams()
+    model = build_model(dx, hp).eval()
+    sd = helpers.golden_state_dict()
+    synth = GraphedSynthesizer(model, hp)
+    g = torch.Generator().manual_seed(5)
+    for round_, lens in enumerate(([137, 64, 190, 33, 128], [181, 150, 17, 127, 66])):      # same (R, T bucket): the second replays
+        R, T = len(lens), max(lens)
+        lengths = torch.tensor(lens)
+        valid = (torch.arange(T)[None, :] < lengths[:, None]).float()
+        mel = torch.randn(R, hp.n_mel_channels, T, generator=g) * valid[:, None, :]
+        energy = torch.rand(R, T, generator=g) * valid
+        pitch = torch.randn(R, T, generator=g).masked_fill(torch.rand(R, T, generator=g) < 0.3, 0.0) * valid
+        got = synth.accent_embeddings(energy.to(DEV), pitch.to(DEV), mel.to(DEV), lengths.to(DEV), use_graph=use_graph).cpu()
+        assert got.shape == (R, 128)
+        for r, n in enumerate(lens):
+            with torch.no_grad():
+                ref = oracle.accent_encoder(sd, energy[r:r + 1, :n], pitch[r:r + 1, :n], mel[r:r + 1, :, :n], torch.tensor([n]), hp)
+                own = model.accent_encoder(energy[r:r + 1, :n].to(DEV).contiguous(), pitch[r:r + 1, :n].to(DEV).contiguous(),
+                                           mel[r:r + 1, :, :n].to(DEV).contiguous(), torch.tensor([n], device=DEV)).cpu()
+            err = float((got[r] - ref[0]).abs().max())
+            assert err < 2e-5, (round_, r, n, err)
+            assert float((got[r] - own[0]).abs().max()) < 2e-6, (round_, r, n)
+        mean = synth.accent_embedding(energy.to(DEV), pitch.to(DEV), mel.to(DEV), lengths.to(DEV), use_graph=use_graph).cpu()
+        assert mean.shape == (1, 128) and torch.allclose(mean[0], got.mean(dim=0), atol=1e-6)
+    if use_graph:
+        assert len(synth.accent_graphs) == 1
+
+
 def test_batch_conditioning_matches_reference_semantics(dx):
     """f-2: per-speaker zero-preserving z-normalisation + support-set embedding, on the device, vs the host-loop restatement."""
     from oracle import daft_exprt_oracle as oracle

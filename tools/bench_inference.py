@@ -1,51 +1,79 @@
-"""Config 4 (BASELINE.json): inference prosody transfer, batch = 256 sentences, decoder T ~ 800; eager launches vs graph replay."""
-import os, sys, time
+"""Config 4 (BASELINE.json): inference prosody transfer, batch = 256 sentences, decoder T ~ 800 -- including the reference-recording
+leg (accent encoder over the reference mels, scripts/synthesize.py:420-448): eager launches vs graph replay, JSON lines.
+
+    python tools/bench_inference.py [f32|bf16|fp16] [n_reference_recordings=8] [out.json]
+"""
+import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import ubisoft_laforge_daft_exprt_amd as pkg
 from ubisoft_laforge_daft_exprt_amd.inference import GraphedSynthesizer
-from ubisoft_laforge_daft_exprt_amd.synth import synthetic_state_dict
+from ubisoft_laforge_daft_exprt_amd.synth import synthetic_inference_batch, synthetic_state_dict
+
+
+def timed(fn, n=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
 
 
 def main():
     prec = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
+    R = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     pkg.set_precision(prec)
     dev = 'cuda'
     hp = pkg.HyperParams(n_speakers=2, stats={'spk 0': {'pitch': {'mean': 5.0, 'std': 0.25}}})
     model = pkg.DaftExprt(hp).to(dev)
     model.load_state_dict(synthetic_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 1234))
     synth = GraphedSynthesizer(model, hp)
-    g = torch.Generator().manual_seed(1238)
-    B = 256
-    lens = torch.randint(60, 101, (B,), generator=g); lens[0] = 100
-    lens, _ = torch.sort(lens, descending=True)
-    L = 100
-    valid = torch.arange(L)[None, :] < lens[:, None]
-    symbols = (torch.randint(1, 76, (B, L), generator=g) * valid).to(dev)
-    dur = ((0.05 + 0.09 * torch.rand(B, L, generator=g)) * valid).to(dev)
-
-    def args():
-        inputs = (symbols, torch.ones(B, L, device=dev), torch.ones(B, L, device=dev), torch.zeros(B, L, device=dev), lens.to(dev),
-                  torch.zeros(B, dtype=torch.long, device=dev))
-        prosody = {'duration_preds': dur.clone(), 'durations_int': torch.zeros(B, L, dtype=torch.long, device=dev),
-                   'energy_preds': (torch.randn(B, L, generator=g) * valid).to(dev), 'pitch_preds': (torch.randn(B, L, generator=g) * valid).to(dev)}
-        return inputs, 'add', prosody, torch.randn(B, 192, generator=g).to(dev), (0.3 * torch.randn(B, 128, generator=g)).to(dev)
+    inputs, prosody, spk, accent = synthetic_inference_batch()
+    B, L = inputs[0].shape
+    mv = lambda t: t.clone().to(dev)
+    args = lambda: (tuple(mv(t) for t in inputs), 'add', {k: mv(v) for k, v in prosody.items()}, mv(spk), mv(accent))
 
     a = args()
-    t0 = time.perf_counter(); prep = synth.prepare(a[0], a[1], {k: v.clone() for k, v in a[2].items()}); t_host = time.perf_counter() - t0
+    t0 = time.perf_counter(); prep = synth.prepare(a[0], a[1], a[2]); t_host = time.perf_counter() - t0
     frames = sum(prep['out_host'])
+    out = {'precision': prec, 'B': B, 'L_max': L, 'T_max': prep['n_frames'], 'valid_frames': frames, 'host_duration_math_ms': round(t_host * 1e3, 2)}
     for mode in (False, True):
-        for _ in range(2):
-            synth(*args(), use_graph=mode)
-        torch.cuda.synchronize()
-        n = 5
-        t0 = time.perf_counter()
-        for _ in range(n):
-            out = synth(*args(), use_graph=mode)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n
-        print(f'{prec} B={B} L_max={L} T_max={prep["n_frames"]} frames={frames}: {"graph replay" if mode else "eager      "} '
-              f'{dt * 1e3:7.2f} ms/batch incl. host duration math ({t_host * 1e3:.1f} ms) -> {frames / dt / 1e6:.2f} M frames/s')
+        dt = timed(lambda: synth(*args(), use_graph=mode))
+        out['graph_replay' if mode else 'eager'] = {'ms_per_batch': round(dt * 1e3, 3), 'frames_per_s': round(frames / dt)}
+    # reference-recording leg: R recordings of 300-800 frames -> one averaged accent embedding
+    g = torch.Generator().manual_seed(7)
+    lens = torch.randint(300, 801, (R,), generator=g)
+    T = int(lens.max())
+    valid = (torch.arange(T)[None, :] < lens[:, None]).float()
+    mel = (torch.randn(R, hp.n_mel_channels, T, generator=g) * valid[:, None, :]).to(dev)
+    energy, pitch = (torch.rand(R, T, generator=g) * valid).to(dev), (torch.randn(R, T, generator=g) * valid).to(dev)
+    lens_d = lens.to(dev)
+
+    def one_by_one():                                       # the reference's loop: B = 1 per recording, then the mean
+        embs = []
+        with torch.no_grad():
+            for r in range(R):
+                n = int(lens[r])
+                embs.append(model.accent_encoder(energy[r:r + 1, :n].contiguous(), pitch[r:r + 1, :n].contiguous(), mel[r:r + 1, :, :n].contiguous(),
+                                                 lens_d[r:r + 1]))
+        return torch.cat(embs).mean(dim=0, keepdim=True)
+
+    ref_frames = int(lens.sum())
+    leg = {'recordings': R, 'frames': ref_frames}
+    for name, fn in (('per_recording_b1', one_by_one), ('batched_eager', lambda: synth.accent_embedding(energy, pitch, mel, lens_d, use_graph=False)),
+                     ('batched_graph', lambda: synth.accent_embedding(energy, pitch, mel, lens_d, use_graph=True))):
+        dt = timed(fn)
+        leg[name] = {'ms': round(dt * 1e3, 3), 'frames_per_s': round(ref_frames / dt)}
+    out['accent_encoder_leg'] = leg
+    e2e = out['graph_replay']['ms_per_batch'] + leg['batched_graph']['ms']
+    out['end_to_end_graph'] = {'ms': round(e2e, 3), 'frames_per_s': round(frames / (e2e * 1e-3))}
+    print(json.dumps(out))
+    if len(sys.argv) > 3:
+        with open(sys.argv[3], 'w') as f:
+            json.dump(out, f, indent=1)
 
 
 if __name__ == '__main__':

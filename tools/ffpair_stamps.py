@@ -40,7 +40,7 @@ def main():
     wa, wb = (i2.bwd, i1.bwd) if backward else (i1.fwd, i2.fwd)
     for _ in range(3):
         rc = dll.dx_ff_pair(P(x), 128, P(wa), P(wb), P(None if backward else b1), P(None if backward else b2), P(aux), Fc, P(h), Fc, P(y), 128,
-                            B, N, Fc, int(not backward), int(backward), P(lens), 1, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                            B, N, Fc, int(not backward), int(backward), P(lens), 1, P(None), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert rc == 0
     torch.cuda.synchronize()
     st = stamps.cpu()

@@ -45,6 +45,7 @@ struct FFPairArgs {
   int B, N, F;
   int accumulate;
   const int* lens; int skip_halo;
+  const int* rows_exist;             // optional [B]: input / hidden rows n >= rows_exist[b] do not exist (see dx_gemm.hip ConvGemmArgs)
   unsigned long long* stamps;        // diagnostic builds (-DDX_FFPAIR_STAMPS, tools/ffpair_stamps.py) only: [workgroup][role][16] s_memtime values
 };
 
@@ -180,7 +181,8 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
     return;
   }
 
-  // ---- stage the activation tile: rows p = 0..129 <-> n = n0 - 2 + p, zero outside [0, N) ---------------------------------
+  const int NL = a.rows_exist ? a.rows_exist[b] : a.N;   // rows of this batch row that exist for the two convolutions
+  // ---- stage the activation tile: rows p = 0..129 <-> n = n0 - 2 + p, zero outside [0, NL) --------------------------------
   {
     f32x4 xr[5];
 #pragma unroll
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
       const int row = u >> 4, q = u & 15;
       const int n = n0 - 2 + row;
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (u < FP_HR * 16 && n >= 0 && n < a.N) v = *reinterpret_cast<const f32x4*>(a.X + ((size_t)b * a.N + n) * a.ldx + q * 8);
+      if (u < FP_HR * 16 && n >= 0 && n < NL) v = *reinterpret_cast<const f32x4*>(a.X + ((size_t)b * a.N + n) * a.ldx + q * 8);
       xr[it] = v;
     }
     FP_WLOAD(0, 0) FP_WLOAD(1, 1) FP_WLOAD(2, 2) FP_WLOAD(3, 3)      // first weight fragments: in flight beside the tile loads
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
   if (role == 0) {
     f32x4 acc[2][8];
     // hidden rows outside [0, N) are the second conv's zero padding: only the first / last tile of a batch row has any
-    const bool edge = n0 == 0 || n0 + FP_TOK >= a.N;
+    const bool edge = n0 == 0 || n0 + FP_TOK >= NL;
     // bias + ReLU (forward) or the sign mask (backward), bf16, into slice image f & 1
 #define FP_PRODUCE(F_, COFLAG)                                                                                       \
     {                                                                                                                \
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
           if constexpr (AUX) {                                                                                       \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) if (!((float)av[i][j][e] > 0.f)) v[e] = 0.f;               \
           }                                                                                                          \
-          if (edge) { const int n = n0 - 1 + 16 * j + r_; if (n < 0 || n >= a.N) v = f32x4{0.f, 0.f, 0.f, 0.f}; }    \
+          if (edge) { const int n = n0 - 1 + 16 * j + r_; if (n < 0 || n >= NL) v = f32x4{0.f, 0.f, 0.f, 0.f}; }    \
           uint2 pk = fp_pack4(v[0], v[1], v[2], v[3]);                                                               \
           if constexpr (RELU) {                                                                                      \
             /* ReLU on the packed bf16 pairs: a negative float has its sign bit set, i.e. is a negative int16: max(., 0) zeroes it */ \
@@ -442,7 +444,7 @@ extern "C" {
 // skip_halo: token tiles that start at or beyond min(lens[b] + skip_halo, N) are padding nobody reads: zero-filled, not computed.
 int dx_ff_pair(const void* X, int ldx, const void* Wa, const void* Wb, const float* bias_a, const float* bias_b,
                const void* aux, int ld_aux, void* H, int ldh, float* Y, int ldy,
-               int B, int N, int F, int relu_mid, int accumulate, const int* lens, int skip_halo, void* stream) {
+               int B, int N, int F, int relu_mid, int accumulate, const int* lens, int skip_halo, const int* rows_exist, void* stream) {
   DX_REQUIRE(X && Wa && Wb && H && Y, "dx_ff_pair: null pointer");
   DX_REQUIRE(B > 0 && N > 0 && F >= 128 && (F % 128) == 0, "dx_ff_pair: bad dims B=%d N=%d F=%d (F must be a multiple of 128)", B, N, F);
   DX_REQUIRE(ldx >= 128 && (ldx % 8) == 0 && ldh >= F && (ldh % 8) == 0 && ldy >= 128 && (ldy % 4) == 0, "dx_ff_pair: bad leading dimensions");
@@ -452,7 +454,7 @@ int dx_ff_pair(const void* X, int ldx, const void* Wa, const void* Wb, const flo
   DX_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)Wa % 16) == 0 && ((uintptr_t)Wb % 16) == 0 && ((uintptr_t)H % 16) == 0 &&
              ((uintptr_t)Y % 16) == 0 && ((uintptr_t)aux % 8) == 0, "dx_ff_pair: pointers must be 16-byte aligned");
   FFPairArgs a{(const dx_h16*)X, ldx, (const dx_h16*)Wa, (const dx_h16*)Wb, bias_a, bias_b, (const dx_h16*)aux, ld_aux,
-               (dx_h16*)H, ldh, Y, ldy, B, N, F, accumulate, lens, skip_halo, nullptr};
+               (dx_h16*)H, ldh, Y, ldy, B, N, F, accumulate, lens, skip_halo, rows_exist, nullptr};
 #ifdef DX_FFPAIR_STAMPS
   a.stamps = g_ffpair_stamps;
 #endif

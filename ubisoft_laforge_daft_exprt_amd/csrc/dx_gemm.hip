@@ -45,6 +45,10 @@ struct ConvGemmArgs {
   float out_scale;
   int skip_halo;   // >= 0: token tiles starting at or beyond min(len_b + skip_halo, N) are not computed (zero-filled)
   int x_bf16, y_bf16, aux_bf16;   // storage type of X / Y / relu_aux (bf16 operand mode only); ld* are in elements
+  // Optional [B]: input rows n >= rows_exist[b] of batch row b DO NOT EXIST (they read as the conv's zero padding), although the
+  // buffers have N rows per batch row.  NULL = every row has N rows (the reference's padded grid).  Lets one allocation (and one
+  // captured graph) serve batches whose logical padded length is smaller than N, and lets a batch row behave as if it were alone.
+  const int* rows_exist;
 };
 
 template <typename T> struct Mma;
@@ -125,6 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
   const int wc = wave >> 1, wt = wave & 1;
   const int r = lane & 15, g = lane >> 4;
   const T* Wp = reinterpret_cast<const T*>(a.Wp);
+  const int NL = a.rows_exist ? a.rows_exist[b] : a.N;     // rows of this batch row that exist as conv input
 
   if (a.skip_halo >= 0 && n0 >= a.lens[b] + a.skip_halo) {
     // whole tile is padding beyond the halo: nothing downstream reads it with a non-zero weight; keep it defined
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmArgs a)
       const int row = u / XU, q = u % XU;                                                                                        \
       const int n = n0 + row - PAD, ci = ci0_ + q * XE;                                                                          \
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                                                       \
-      if (u < XROWS * XU && n >= 0 && n < a.N && ci < a.Cin) {                                                                   \
+      if (u < XROWS * XU && n >= 0 && n < NL && ci < a.Cin) {                                                                    \
         if constexpr (XH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const dx_h16*>(a.X) + ((size_t)b * a.N + n) * a.ldx + ci); \
         else v = *reinterpret_cast<const f32x4*>(a.X + ((size_t)b * a.N + n) * a.ldx + ci);                                      \
       }                                                                                                                          \
@@ -392,12 +397,13 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, i
   }
   f32x4 xreg[X_IT];
 #define DX_WS_LOAD(B_, N0_)                                                                                          \
+  const int nl_ = a.rows_exist ? a.rows_exist[B_] : a.N;                                                             \
   _Pragma("unroll") for (int it = 0; it < X_IT; ++it) {                                                              \
     const int u = tid + it * 512;                                                                                    \
     const int row = u / XU, q = u % XU;                                                                              \
     const int n = (N0_) + row - PAD, ci = q * XE;                                                                    \
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                                             \
-    if (u < XROWS * XU && n >= 0 && n < a.N && ci < a.Cin) {                                                         \
+    if (u < XROWS * XU && n >= 0 && n < nl_ && ci < a.Cin) {                                                         \
       if constexpr (XH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const dx_h16*>(a.X) + ((size_t)(B_) * a.N + n) * a.ldx + ci); \
       else v = *reinterpret_cast<const f32x4*>(a.X + ((size_t)(B_) * a.N + n) * a.ldx + ci);                         \
     }                                                                                                                \
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, i
 
   int t = blockIdx.x, b = 0, n0 = 0;
   bool live = next_tile(t, b, n0);
-  if (live) DX_WS_LOAD(b, n0)
+  if (live) { DX_WS_LOAD(b, n0) }
   while (live) {
     const int cb = b, cn0 = n0;
     __syncthreads();                                       // previous tile's fragment reads are done (and W is in place)
@@ -453,7 +459,7 @@ __global__ __launch_bounds__(512, 2) void conv_ws_kernel(const ConvGemmArgs a, i
     __syncthreads();
     t += wgs_per_cotile;
     live = next_tile(t, b, n0);
-    if (live) DX_WS_LOAD(b, n0)
+    if (live) { DX_WS_LOAD(b, n0) }
     // ReLU-gradient mask of THIS tile (input gradient of FF conv2: the bf16 hidden tensor): requested before the matrix block so
     // that the copy-out below does not start with a dependent global load
     // (k = 3 only: the k = 1 instantiations would lose a wave per SIMD to the 16 extra registers)
@@ -724,6 +730,7 @@ __global__ __launch_bounds__(512) void conv_dk_kernel(const ConvGemmArgs a) {
   }
 
   const int nchunks = a.CinP / 64;
+  const int NL = a.rows_exist ? a.rows_exist[b] : a.N;              // rows of this batch row that exist as conv input
   // Every staging access is unconditional (addresses are clamped, zeros are selected in when the value is stored): loads
   // inside divergent branches make the compiler give up counting vmcnt and drain the whole prefetch queue at each use.
   // Addresses are a wave-uniform base (scalar unit) + a 32-bit per-thread element offset: no vector arithmetic per load (the
@@ -735,11 +742,11 @@ __global__ __launch_bounds__(512) void conv_dk_kernel(const ConvGemmArgs a) {
     const int u = min(tid + it * 512, XROWS * XU - 1);              // surplus slots repeat the last unit (same value, same place)
     const int row = u / XU, q = u % XU;
     const int n = n0 + row - PAD;
-    xpad[it] = n < 0 || n >= a.N;
+    xpad[it] = n < 0 || n >= NL;
     xoff[it] = xpad[it] ? q * XE : (b * a.N + n) * a.ldx + q * XE;
     xlds[it] = XH ? lds_off(row, q) : lds_off(row, q >> 1) + ((q & 1) << 3);
   }
-  const bool edge_tile = n0 < PAD || n0 + TOK + PAD > a.N;          // wave-uniform
+  const bool edge_tile = n0 < PAD || n0 + TOK + PAD > NL;           // wave-uniform
   // fragment (tap, i) of stage ch: element offset wbase + ((tap * (CoutP/16) + i) * (CinP/32) + 2 * ch) * 512
   const dx_h16* const wwave = Wp + ((size_t)((co0 >> 4) + wq * 2) * (a.CinP >> 5) + kg) * 512;      // wave-uniform
   const size_t wtap = (size_t)(a.CoutP >> 4) * (a.CinP >> 5) * 512, wrow = (size_t)(a.CinP >> 5) * 512;
@@ -1550,7 +1557,7 @@ int dx_conv_gemm(const void* Xv, int ldx, const void* Wp, const float* bias, voi
                  int relu, const float* post_scale, const float* post_shift,
                  const void* relu_auxv, int ld_aux, int accumulate,
                  const int* lens, int mask_rows, float out_scale, int skip_halo,
-                 int x_bf16, int y_bf16, int aux_bf16, void* stream) {
+                 int x_bf16, int y_bf16, int aux_bf16, const int* rows_exist, void* stream) {
   const float* X = (const float*)Xv; float* Y = (float*)Yv; const float* relu_aux = (const float*)relu_auxv;
   DX_REQUIRE(X && Wp && Y, "dx_conv_gemm: null pointer");
   DX_REQUIRE(bf16 || !(x_bf16 || y_bf16 || aux_bf16), "dx_conv_gemm: bf16 storage needs bf16 operand mode");
@@ -1569,7 +1576,7 @@ int dx_conv_gemm(const void* Xv, int ldx, const void* Wp, const float* bias, voi
   int d[4];
   dx_pack_dims(Cout, Cin, bf16, d);
   ConvGemmArgs a{X, ldx, Wp, bias, Y, ldy, B, N, Cin, Cout, d[1], d[0], relu, post_scale, post_shift,
-                 relu_aux, ld_aux, accumulate, lens, mask_rows, out_scale, skip_halo, x_bf16, y_bf16, aux_bf16};
+                 relu_aux, ld_aux, accumulate, lens, mask_rows, out_scale, skip_halo, x_bf16, y_bf16, aux_bf16, rows_exist};
   hipStream_t s = (hipStream_t)stream;
   dx_prof_begin(DX_PROF_CONV_GEMM, s);
   static const int use_ws = getenv("DX_CONV_WS") ? atoi(getenv("DX_CONV_WS")) : 1;

@@ -56,6 +56,11 @@ class Lengths:
         self.total = sum(self.host)
         self.i32 = lengths.to(dtype=torch.int32).contiguous()
         self.i64 = lengths
+        # optional device int32 [B]: rows n >= exist[b] of utterance b do not exist for the k = 3 convolutions (they read zero), although
+        # the tensors have more rows.  None = the reference's padded grid (every utterance has max(lengths) rows).  Set by
+        # inference.GraphedSynthesizer: padded-shape buckets (exist = the batch's true longest length) and the batched accent encoder
+        # (exist = lengths: every reference behaves as if it were run alone, scripts/synthesize.py:420-448).
+        self.exist = None
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -163,10 +168,10 @@ class FFTBlockFn(torch.autograd.Function):
         y1g = ln1[3] if sh else y1                 # the copy the GEMMs read
         fused = ops.ff_pair_applies(y1g, packs['c1'], packs['c2'], prec)
         if fused:      # conv1 + ReLU + conv2 in ONE launch, the 1024-wide hidden tile consumed from LDS (h is still written: weight gradients)
-            z2, h = ops.ff_pair(y1g, packs['c1'], packs['c2'], c1_b, c2_b, L, prec=prec)
+            z2, h = ops.ff_pair(y1g, packs['c1'], packs['c2'], c1_b, c2_b, L, prec=prec, rows_exist=lens.exist)
         else:
-            h = ops.conv_gemm(y1g, packs['c1'], c1_b, relu=True, lens=L, halo=1, out_dtype=hd, prec=prec)   # conv2 reads one row past the end
-            z2 = ops.conv_gemm(h, packs['c2'], c2_b, lens=L, halo=0, prec=prec)
+            h = ops.conv_gemm(y1g, packs['c1'], c1_b, relu=True, lens=L, halo=1, out_dtype=hd, prec=prec, rows_exist=lens.exist)   # conv2 reads one row past the end
+            z2 = ops.conv_gemm(h, packs['c2'], c2_b, lens=L, halo=0, prec=prec, rows_exist=lens.exist)
         y2, mean2, rstd2 = ops.ln_fwd(z2, y1, ln2_w, ln2_b, film, lens.i32, seed_pre=s_ln2, p_pre=p_conv, seed_offset=so, prec=prec)
         ctx.save_for_backward(x, film, qkv, att, lse, z1, mean1, rstd1, y1g, h, z2, mean2, rstd2, ln1_w, ln1_b, ln2_w, ln2_b)
         ctx.lens, ctx.packs, ctx.heads = lens, packs, heads
@@ -178,6 +183,8 @@ class FFTBlockFn(torch.autograd.Function):
     def backward(ctx, dy2):
         x, film, qkv, att, lse, z1, mean1, rstd1, y1, h, z2, mean2, rstd2, ln1_w, ln1_b, ln2_w, ln2_b = ctx.saved_tensors
         lens, packs = ctx.lens, ctx.packs
+        if lens.exist is not None:
+            raise NotImplementedError('Lengths.exist (padded-shape buckets / stand-alone rows) is a forward-only feature')
         p_attn, p_conv, s_attn, s_ln1, s_ln2 = ctx.drop
         dy2 = dy2.contiguous()
         L = lens.i32
@@ -231,11 +238,11 @@ class AccentFrontFn(torch.autograd.Function):
         prec = rt.precision
         hd = ops.hidden_dtype(prec)                                           # 1024-wide tensors: bf16 in bf16 operand mode
         so = rt.seed_offset
-        h0 = ops.conv_gemm(x0, packs['p0'], c0_b, relu=True, lens=L, halo=2, out_dtype=hd, prec=prec)   # three stacked k=3 convs: halos 2, 1, 0
+        h0 = ops.conv_gemm(x0, packs['p0'], c0_b, relu=True, lens=L, halo=2, out_dtype=hd, prec=prec, rows_exist=lens.exist)   # three stacked k=3 convs: halos 2, 1, 0
         y0, m0, r0 = ops.ln_fwd(h0, None, l0_w, l0_b, None, L, seed_post=seeds[0], p_post=p, halo=2, seed_offset=so, prec=prec)
-        h1 = ops.conv_gemm(y0, packs['p1'], c1_b, relu=True, lens=L, halo=1, out_dtype=hd, prec=prec)
+        h1 = ops.conv_gemm(y0, packs['p1'], c1_b, relu=True, lens=L, halo=1, out_dtype=hd, prec=prec, rows_exist=lens.exist)
         y1, m1, r1 = ops.ln_fwd(h1, None, l1_w, l1_b, None, L, seed_post=seeds[1], p_post=p, halo=1, seed_offset=so, prec=prec)
-        h2 = ops.conv_gemm(y1, packs['p2'], c2_b, relu=True, lens=L, halo=0, prec=prec)
+        h2 = ops.conv_gemm(y1, packs['p2'], c2_b, relu=True, lens=L, halo=0, prec=prec, rows_exist=lens.exist)
         y2, m2, r2 = ops.ln_fwd(h2, None, l2_w, l2_b, None, L, seed_post=seeds[2], p_post=p, halo=0, seed_offset=so, prec=prec)
         energy, pitch = energy.contiguous(), pitch.contiguous()
         out = ops.accent_sum(y2, energy, pitch, we, be, wp, bp, pe, lens.i32)

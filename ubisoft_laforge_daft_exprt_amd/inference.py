@@ -3,10 +3,20 @@
 ``DaftExprt.inference`` (reference model.py:1026-1114) interleaves host work (``get_int_durations``: double-precision
 Python, ``.item()`` loops; ``int(torch.max(...))``; asserts) with device work, which blocks graph capture.
 Here the host part runs FIRST (durations -> integer frames, lengths, T_max, all bit-exact and on the CPU), then the whole
-device part -- speaker projection, FiLM generation, phoneme encoder, Gaussian upsampler, frame decoder -- is one
-captured HIP graph per (B, L_max, T_max) shape, replayed with new inputs copied into its static buffers.
-Lengths are device inputs of the graph, so batches with different per-utterance lengths but the same padded shape
-replay the same graph.
+device part -- speaker projection, FiLM generation, phoneme encoder, Gaussian upsampler, frame decoder -- is ONE captured HIP
+graph per shape BUCKET, replayed with new inputs copied into its static buffers.
+
+Length bucketing.  A graph is keyed by (B, L_max rounded up to 16, T_max rounded up to 64), not by the exact padded shape: every
+new T_max would otherwise re-capture.  The reference's results depend on the padded length (the k = 3 convolutions see zero
+padding at the end of the (B, N_max) grid), so the kernels are told separately how many rows EXIST
+(``Lengths.exist`` -> the ``rows_exist`` argument of the C ABI: device memory, re-read by every replay) and how many are
+allocated (the tensor shape): rows in between are treated exactly like the reference's non-existent ones, and a replay at any
+(L_max, T_max) inside the bucket equals the eager forward at that exact shape.
+
+Batched accent encoder.  The reference obtains the accent embedding by running ``model.accent_encoder`` on each reference
+recording with B = 1 and averaging (scripts/synthesize.py:420-448).  ``accent_embedding`` runs all recordings as one padded batch
+with ``exist = lengths``: every row sees no padding at all, i.e. behaves as if it were run alone, so the batch reproduces the
+per-recording results.
 """
 from __future__ import annotations
 
@@ -15,12 +25,20 @@ import torch
 from . import ops
 from .functional import Lengths
 
+L_STEP, T_STEP = 16, 64
+
+
+def _up(n, step):
+    return (int(n) + step - 1) // step * step
+
 
 class GraphedSynthesizer:
-    def __init__(self, model, hparams):
+    def __init__(self, model, hparams, max_graphs=32):
         self.model = model.eval()
         self.hparams = hparams
         self.graphs = {}
+        self.accent_graphs = {}
+        self.max_graphs = max_graphs
 
     # -- host side: exactly the reference's pre-processing, model.py:1068-1087 --------------------------------------------
     def prepare(self, inputs, pitch_transform, external_prosody):
@@ -49,33 +67,46 @@ class GraphedSynthesizer:
         spk = m.spk_projection(ops.l2_normalize(st['spk_embs']), need_dx=False)
         film = m.style_adapter(st['accent_emb'] + spk)
         in_lens = Lengths(st['in_lens'], host=st['in_host'])
-        in_lens.i32 = st['in_lens_i32']
+        in_lens.i32, in_lens.exist = st['in_lens_i32'], st.get('in_exist')
         enc = m.phoneme_encoder(st['symbols'], film['phoneme_encoder'], in_lens)
         x, weights = m.gaussian_upsampling(enc, st['dur'], st['dur_int'], st['energy'], st['pitch'], in_lens, n_frames=st['n_frames'])
         out_lens = Lengths(st['out_lens'], host=st['out_host'])
-        out_lens.i32 = st['out_lens_i32']
+        out_lens.i32, out_lens.exist = st['out_lens_i32'], st.get('out_exist')
         mel = m.frame_decoder(x, film['frame_decoder'], out_lens)
         return mel, weights
+
+    @staticmethod
+    def _evict(cache, limit):
+        if len(cache) >= limit:
+            del cache[min(cache, key=lambda k: cache[k]['hits'])]
 
     def __call__(self, inputs, pitch_transform, external_prosody, external_embeddings, external_accent_emb, use_graph=True):
         """Same arguments as ``DaftExprt.inference``; returns the same triple."""
         prep = self.prepare(inputs, pitch_transform, external_prosody)
         dev = prep['symbols'].device
         out_lens = torch.tensor(prep['out_host'], dtype=torch.long, device=dev)
+        B, L = prep['symbols'].shape
+        T = prep['n_frames']
         live = dict(symbols=prep['symbols'].contiguous(), dur=prep['dur'].contiguous(), dur_int=prep['dur_int'].contiguous(),
                     energy=prep['energy'].contiguous(), pitch=prep['pitch'].contiguous(), in_lens=prep['in_lens'],
                     in_lens_i32=prep['in_lens'].to(torch.int32), out_lens=out_lens, out_lens_i32=out_lens.to(torch.int32),
                     spk_embs=external_embeddings.contiguous(), accent_emb=external_accent_emb.contiguous())
-        meta = dict(in_host=prep['in_host'], out_host=prep['out_host'], n_frames=prep['n_frames'])
-        B, L = prep['symbols'].shape
-        key = (B, L, prep['n_frames'], max(prep['out_host']))
         with torch.no_grad():
             if not use_graph:
-                mel, weights = self._device_forward({**live, **meta})
+                mel, weights = self._device_forward({**live, 'in_host': prep['in_host'], 'out_host': prep['out_host'], 'n_frames': T})
             else:
+                Lb, Tb = _up(L, L_STEP), _up(max(T, 1), T_STEP)
+                key = (B, Lb, Tb, self.model.runtime.precision)
                 entry = self.graphs.get(key)
                 if entry is None:
-                    static = {k: v.clone() for k, v in live.items()}
+                    static = {k: (torch.zeros(B, Lb, dtype=v.dtype, device=dev) if k in ('symbols', 'dur', 'dur_int', 'energy', 'pitch') else v.clone())
+                              for k, v in live.items()}
+                    static['in_exist'] = torch.full((B,), L, dtype=torch.int32, device=dev)      # rows that EXIST on each axis: re-read by
+                    static['out_exist'] = torch.full((B,), T, dtype=torch.int32, device=dev)    # every replay (set per call below)
+                    for k in ('symbols', 'dur', 'dur_int', 'energy', 'pitch'):
+                        static[k][:, :L].copy_(live[k])
+                    # host-side shape metadata of the BUCKET (lengths as Python ints only size tensors here)
+                    meta = dict(in_host=[Lb] * B, out_host=[Tb] * B, n_frames=Tb)
                     stream = torch.cuda.Stream()
                     stream.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(stream):                       # warm-up: packs weights, sets kernel attributes
@@ -84,14 +115,76 @@ class GraphedSynthesizer:
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph):
                         outs = self._device_forward({**static, **meta})
-                    entry = (graph, static, outs)
+                    self._evict(self.graphs, self.max_graphs)
+                    entry = dict(graph=graph, static=static, outs=outs, hits=0)
                     self.graphs[key] = entry
-                graph, static, outs = entry
+                entry['hits'] += 1
+                static, outs = entry['static'], entry['outs']
                 ops.repack_all(self.model.runtime)        # weights changed since capture (load_state_dict, an optimiser step)? one
                                                           # launch rewrites the SAME pack buffers the captured kernels read
-                for k, v in live.items():
-                    static[k].copy_(v)
-                graph.replay()
-                mel, weights = outs[0].clone(), outs[1].clone()
+                for k in ('symbols', 'dur', 'dur_int', 'energy', 'pitch'):
+                    static[k].zero_()
+                    static[k][:, :L].copy_(live[k])
+                for k in ('in_lens', 'in_lens_i32', 'out_lens', 'out_lens_i32', 'spk_embs', 'accent_emb'):
+                    static[k].copy_(live[k])
+                static['in_exist'].fill_(L)
+                static['out_exist'].fill_(T)
+                entry['graph'].replay()
+                mel, weights = outs[0][:, :, :T].clone(), outs[1][:, :L, :T].clone()
         encoder_preds = [prep['dur'], prep['dur_int'], prep['energy'], prep['pitch'], prep['in_lens']]
         return encoder_preds, [mel, out_lens], weights
+
+    # -- batched accent encoder ----------------------------------------------------------------------------------------------
+    def accent_embeddings(self, frames_energy, frames_pitch, mel_specs, lengths, use_graph=True):
+        """(R, T) energy / pitch, (R, n_mel, T) mels and (R,) lengths of R reference recordings, right-zero-padded -> (R, 128): row r
+        is what ``model.accent_encoder`` returns for recording r run ALONE (B = 1, no padding), as scripts/synthesize.py:420-448 does."""
+        m = self.model
+        dev = mel_specs.device
+        R, n_mel, T = mel_specs.shape
+        lengths = lengths.to(dev)
+        host = lengths.tolist()
+        i32 = lengths.to(torch.int32)
+
+        def run(e, p, mel, lens_t, lens_i32, host_lens):
+            lens = Lengths(lens_t, host=host_lens)
+            lens.i32 = lens_i32
+            lens.exist = lens_i32                       # rows beyond a recording's own length do not exist: it behaves as if alone
+            return m.accent_encoder(e, p, mel, lens)
+
+        with torch.no_grad():
+            if not use_graph:
+                return run(frames_energy.contiguous(), frames_pitch.contiguous(), mel_specs.contiguous(), lengths, i32, host)
+            Tb = _up(T, T_STEP)
+            key = (R, Tb, self.model.runtime.precision)
+            entry = self.accent_graphs.get(key)
+            if entry is None:
+                static = dict(e=torch.zeros(R, Tb, device=dev), p=torch.zeros(R, Tb, device=dev), mel=torch.zeros(R, n_mel, Tb, device=dev),
+                              lens=lengths.clone(), i32=i32.clone())
+                args = lambda: (static['e'], static['p'], static['mel'], static['lens'], static['i32'], [Tb] * R)
+                stream = torch.cuda.Stream()
+                stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(stream):
+                    run(*args())
+                torch.cuda.current_stream().wait_stream(stream)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = run(*args())
+                self._evict(self.accent_graphs, self.max_graphs)
+                entry = dict(graph=graph, static=static, out=out, hits=0)
+                self.accent_graphs[key] = entry
+            entry['hits'] += 1
+            static = entry['static']
+            ops.repack_all(self.model.runtime)
+            for k, v in (('e', frames_energy), ('p', frames_pitch)):
+                static[k].zero_()
+                static[k][:, :T].copy_(v)
+            static['mel'].zero_()
+            static['mel'][:, :, :T].copy_(mel_specs)
+            static['lens'].copy_(lengths)
+            static['i32'].copy_(i32)
+            entry['graph'].replay()
+            return entry['out'].clone()
+
+    def accent_embedding(self, frames_energy, frames_pitch, mel_specs, lengths, use_graph=True):
+        """The averaged accent embedding (1, 128) of scripts/synthesize.py:446-448."""
+        return self.accent_embeddings(frames_energy, frames_pitch, mel_specs, lengths, use_graph).mean(dim=0, keepdim=True)

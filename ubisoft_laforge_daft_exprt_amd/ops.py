@@ -240,7 +240,7 @@ def _log(pack_or_rt, rec):
 
 def conv_gemm(x, pack: PackedWeight, bias=None, *, transpose=False, relu=False, post_scale=None, post_shift=None,
               relu_aux=None, out=None, accumulate=False, lens=None, mask_rows=False, out_scale=1.0, B=None, N=None, halo=-1,
-              out_dtype=torch.float32, prec=None):
+              out_dtype=torch.float32, prec=None, rows_exist=None):
     """y = epilogue(conv(x)).  ``transpose=True`` runs the input-gradient convolution (x is dY, result is dX).
     ``prec``: operand precision (default: the pack's runtime); backward passes hand in the precision their forward captured."""
     _chk(x, 'x')
@@ -262,7 +262,7 @@ def conv_gemm(x, pack: PackedWeight, bias=None, *, transpose=False, relu=False, 
     _fn('dx_conv_gemm', prec)(_p(x), ldx, _p(img.bwd if transpose else img.fwd), _p(bias), _p(out), ldy, B_, N_, cin, cout, pack.taps,
                        img.half, int(relu), _p(post_scale), _p(post_shift), _p(relu_aux),
                        0 if relu_aux is None else _rows(relu_aux), int(accumulate), _p(lens), int(mask_rows), float(out_scale), int(halo),
-                       _is_bf16(x), _is_bf16(out), _is_bf16(relu_aux), _stream())
+                       _is_bf16(x), _is_bf16(out), _is_bf16(relu_aux), _p(rows_exist), _stream())
     return out
 
 
@@ -279,7 +279,7 @@ def ff_pair_applies(x, pack1: PackedWeight, pack2: PackedWeight, prec) -> bool:
 
 
 def ff_pair(x, pack1: PackedWeight, pack2: PackedWeight, bias1, bias2, lens, *, backward=False, aux=None, out=None, accumulate=False,
-            halo=1, prec=None):
+            halo=1, prec=None, rows_exist=None):
     """The conv feed-forward pair in ONE launch (bf16 operand mode; csrc/dx_ffpair.hip).
     forward : (z, h)  with h = relu(conv1(x) + b1) [bf16, kept for the weight gradients], z = conv2(h) + b2 [fp32]
     backward: (dx, dh) with x = d(loss)/dz as bf16, dh = conv2^T(x) masked by ``aux`` = h > 0 [bf16], dx (+)= conv1^T(dh)
@@ -298,7 +298,7 @@ def ff_pair(x, pack1: PackedWeight, pack2: PackedWeight, bias1, bias2, lens, *, 
         out = torch.empty(B, N, 128, dtype=torch.float32, device=x.device)
     _log(pack1, ('ffpair', B * N, N, 128, Fc, 3))
     _fn('dx_ff_pair', prec)(_p(x), _rows(x), _p(wa), _p(wb), _p(bias1), _p(bias2), _p(aux), 0 if aux is None else _rows(aux), _p(h), _rows(h),
-                     _p(out), _rows(out), B, N, Fc, int(not backward), int(accumulate), _p(lens), int(halo), _stream())
+                     _p(out), _rows(out), B, N, Fc, int(not backward), int(accumulate), _p(lens), int(halo), _p(rows_exist), _stream())
     return out, h
 
 
