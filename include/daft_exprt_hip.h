@@ -35,6 +35,14 @@ const char* dx_last_error(void);
 int dx_prof_enable(int kind, int capacity);
 int dx_prof_collect(int kind, int* launches, double* total_ms);
 
+/* ---- host-side integer durations: DaftExprt.get_int_durations, model.py:950-973 -> duration_to_integer, extract_features.py:69-125 ----
+ * HOST pointers, no GPU work.  dur: (B, L) seconds, already thresholded (values < filter_length / sampling_rate / 2 set to 0);
+ * out: (B, L) frames per symbol; totals[b] = sum of row b; status[b]: 0 ok, 1 the phones ran out before the frames did (the reference
+ * raises IndexError / ValueError for that utterance), 2 count mismatch (the reference's index assignment raises).  Double-precision
+ * arithmetic with int() truncation, operation for operation what the reference's Python does; bit-exact. */
+int dx_int_durations(const float* dur, int B, int L, int sampling_rate, int filter_length, int hop_length, int centered,
+                     long long* out, long long* totals, int* status);
+
 /* ---- Conv1d / Linear as MFMA GEMM: model.py:57-72 (LinearNorm), :75-94 (ConvNorm1D), :165-186 (MHA in/out proj) ---- */
 /* dims[4] = {CoutP_fwd, CinP_fwd, CinP_bwd, CoutP_bwd}: padded sizes of the packed weights (element counts
  * taps*dims[0]*dims[1] and taps*dims[2]*dims[3]); bf16 = 0 packs f32 (exact MFMA), 1 packs bf16 */

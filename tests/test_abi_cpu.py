@@ -92,6 +92,32 @@ def test_duration_rounding_matches_oracle_on_random_rows():
         assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
 
 
+@pytest.mark.parametrize('centered', [False, True])
+def test_host_library_durations_equal_oracle_including_error_rows(centered):
+    """dx_int_durations (C, host) against the oracle's restatement of duration_to_integer (extract_features.py:69-125): bit-exact integers
+    and totals over many scales and sparsities, both window conventions; utterances the reference raises on raise the same exception."""
+    from oracle import daft_exprt_oracle as oracle
+    from ubisoft_laforge_daft_exprt_amd.durations import get_int_durations
+    hp = helpers.golden_hparams().clone(centered=centered)
+    g = torch.Generator().manual_seed(3)
+    ok = raised = 0
+    for trial in range(60):
+        L = int(torch.randint(1, 60, (1,), generator=g))
+        rows = ((0.01 + 0.3 * torch.rand(4, L, generator=g)) * (0.15 + 0.05 * trial)).float()
+        rows = rows * (torch.rand(4, L, generator=g) > 0.25 * (trial % 3))
+        try:
+            want = oracle.get_int_durations(rows.clone(), hp)
+        except Exception as exc:                     # noqa: BLE001 -- the exception TYPE is the expected value here
+            with pytest.raises(type(exc)):
+                get_int_durations(rows.clone(), hp)
+            raised += 1
+            continue
+        f, i, totals = get_int_durations(rows.clone(), hp, return_totals=True)
+        assert torch.equal(i, want[1]) and torch.equal(f, want[0]) and totals == want[1].sum(dim=1).tolist()
+        ok += 1
+    assert ok >= 20 and raised >= 3, (ok, raised)
+
+
 def test_synthetic_batch_contract():
     from ubisoft_laforge_daft_exprt_amd.synth import CONFIGS, synthetic_batch
     batch = synthetic_batch(**CONFIGS['C1'])

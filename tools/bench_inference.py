@@ -11,7 +11,7 @@ from ubisoft_laforge_daft_exprt_amd.inference import GraphedSynthesizer
 from ubisoft_laforge_daft_exprt_amd.synth import synthetic_inference_batch, synthetic_state_dict
 
 
-def timed(fn, n=5, warm=2):
+def timed(fn, n=20, warm=3):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -33,13 +33,17 @@ def main():
     synth = GraphedSynthesizer(model, hp)
     inputs, prosody, spk, accent = synthetic_inference_batch()
     B, L = inputs[0].shape
-    mv = lambda t: t.clone().to(dev)
-    args = lambda: (tuple(mv(t) for t in inputs), 'add', {k: mv(v) for k, v in prosody.items()}, mv(spk), mv(accent))
+    # inputs resident in HBM before the timed region (the measurement rule of bench.py); every call works on fresh device copies because
+    # inference() transforms the prosody tensors in place, like the reference
+    inputs, prosody, spk, accent = tuple(t.to(dev) for t in inputs), {k: v.to(dev) for k, v in prosody.items()}, spk.to(dev), accent.to(dev)
+    args = lambda: (tuple(t.clone() for t in inputs), 'add', {k: v.clone() for k, v in prosody.items()}, spk.clone(), accent.clone())
 
+    synth.prepare(*args()[:3])                               # first call loads the library
     a = args()
-    t0 = time.perf_counter(); prep = synth.prepare(a[0], a[1], a[2]); t_host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); prep = synth.prepare(a[0], a[1], a[2]); torch.cuda.synchronize(); t_host = time.perf_counter() - t0
     frames = sum(prep['out_host'])
-    out = {'precision': prec, 'B': B, 'L_max': L, 'T_max': prep['n_frames'], 'valid_frames': frames, 'host_duration_math_ms': round(t_host * 1e3, 2)}
+    out = {'precision': prec, 'B': B, 'L_max': L, 'T_max': prep['n_frames'], 'valid_frames': frames, 'host_prepare_ms': round(t_host * 1e3, 2)}
     for mode in (False, True):
         dt = timed(lambda: synth(*args(), use_graph=mode))
         out['graph_replay' if mode else 'eager'] = {'ms_per_batch': round(dt * 1e3, 3), 'frames_per_s': round(frames / dt)}

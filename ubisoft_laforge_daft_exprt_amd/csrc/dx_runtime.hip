@@ -85,4 +85,78 @@ void dx_prof_end(int kind, hipStream_t s) {
   }
 }
 
+
+// ---- host-side integer frame durations ----------------------------------------------------------------------------------------
+// DaftExprt.get_int_durations (reference model.py:950-973) -> duration_to_integer (extract_features.py:69-125), one utterance per row.
+// Plain host code: the reference's arithmetic is Python float (IEEE double) with int() truncation, reproduced operation by operation
+// (no fused multiply-add can form: no product feeds a sum).  The O(frames x phones) scan of the reference is replaced by counting the
+// frame centres filter_length/2 + hop*i, 0 <= i < nb_frames, inside (begin_sample, end_sample] in closed form.
+// status[b]: 0 ok, 1 the phones ran out before the frames did (the reference raises IndexError), 2 the number of integer durations
+// differs from the number of non-zero symbols (the reference's index assignment raises).  Rows with status != 0 are left zero
+// (the Python wrapper re-runs such a row through its own restatement, which raises the reference's exception type).
+#pragma STDC FP_CONTRACT OFF
+static long long dx_centres_upto(long long sample, long long first, long long hop, long long nb_frames) {
+  if (nb_frames <= 0 || sample < first) return 0;
+  const long long n = (sample - first) / hop + 1;
+  return n < nb_frames ? n : nb_frames;
+}
+
+int dx_int_durations(const float* dur, int B, int L, int sampling_rate, int filter_length, int hop_length, int centered,
+                     long long* out, long long* totals, int* status) {
+  DX_REQUIRE(dur && out && totals && status && B >= 0 && L > 0 && sampling_rate > 0 && hop_length > 0, "dx_int_durations: bad arguments");
+  const double sr = (double)sampling_rate;
+  const long long first = (long long)((double)filter_length / 2.0);
+  int bad = 0;
+  for (int b = 0; b < B; ++b) {
+    const float* row = dur + (size_t)b * L;
+    long long* o = out + (size_t)b * L;
+    for (int s = 0; s < L; ++s) o[s] = 0;
+    totals[b] = 0;
+    status[b] = 0;
+    // nb_samples = int(sum(end - begin) * sr): the spans are [end_prev, end_prev + d] with end_prev accumulated in double
+    double end_prev = 0.0, total = 0.0;
+    int n_nonzero = 0;
+    for (int s = 0; s < L; ++s) {
+      const double d = (double)row[s];
+      if (d != 0.0) { const double end = end_prev + d; total += end - end_prev; end_prev += d; ++n_nonzero; }
+    }
+    const long long nb_samples = (long long)(total * sr);
+    const long long nb_frames = 1 + (long long)((double)(nb_samples - filter_length) / (double)hop_length);
+    long long consumed = 1, n_out = 0, first_idx = -1, last_idx = -1;
+    int s = 0;
+    end_prev = 0.0;
+    bool ran_out = false;
+    while (consumed <= nb_frames) {
+      while (s < L && (double)row[s] == 0.0) ++s;
+      if (s >= L) { ran_out = true; break; }
+      const double d = (double)row[s];
+      const double begin = end_prev, end = end_prev + d;
+      end_prev += d;
+      if (begin == end) { ran_out = true; break; }      // the reference raises ValueError; reported as status 1 as well
+      const long long bs = (long long)(begin * sr), es = (long long)(end * sr);
+      const long long n = dx_centres_upto(es, first, hop_length, nb_frames) - dx_centres_upto(bs, first, hop_length, nb_frames);
+      o[s] = n;
+      if (first_idx < 0) first_idx = s;
+      last_idx = s;
+      consumed += n;
+      ++n_out;
+      ++s;
+    }
+    if (ran_out || n_out == 0) { status[b] = 1; ++bad; for (int q = 0; q < L; ++q) o[q] = 0; continue; }
+    long long head, tail;
+    if (centered) { head = tail = (long long)((double)filter_length / 2.0 / (double)hop_length); }
+    else { const long long extra = (long long)((double)(filter_length - hop_length) / (double)hop_length); head = extra / 2; tail = extra - head; }
+    o[first_idx] += head;
+    while (s < L && (double)row[s] == 0.0) ++s;
+    if (s < L) { o[s] = tail; ++n_out; ++s; }        // phones left over: the next one receives the trailing edge frames
+    else o[last_idx] += tail;
+    if (n_out != n_nonzero) { status[b] = 2; ++bad; for (int q = 0; q < L; ++q) o[q] = 0; continue; }
+    long long t = 0;
+    for (int q = 0; q < L; ++q) t += o[q];
+    totals[b] = t;
+  }
+  (void)bad;
+  return 0;                     // per-row conditions are reported in status[], like the reference reports them per utterance
+}
+
 }  // extern "C"

@@ -51,19 +51,38 @@ def duration_to_integer(float_durations, hparams, nb_samples=None):
     return out
 
 
-def get_int_durations(duration_preds: torch.Tensor, hparams):
-    """Zeroes durations under half an FFT window, converts each row; returns (duration_preds, durations_int on the same device)."""
+def _row_to_integer(row, hparams):
+    """One utterance through the Python restatement: (indices of the non-zero symbols, integer durations)."""
+    end_prev, idx, spans = 0.0, [], []
+    for s, d in enumerate(row):
+        if d != 0.0:
+            idx.append(s)
+            spans.append([end_prev, end_prev + d])
+            end_prev += d
+    return idx, duration_to_integer(spans, hparams)
+
+
+def get_int_durations(duration_preds: torch.Tensor, hparams, return_totals=False):
+    """Zeroes durations under half an FFT window, converts each row; returns (duration_preds, durations_int on the same device)
+    [+ the per-utterance frame totals as Python ints: saves the caller a device reduction and a sync].
+
+    The conversion itself is ``dx_int_durations`` of the host library (C, double precision, the same operations in the same order: one
+    pass over the batch instead of a Python loop per symbol).  A row the reference would raise on is re-run through the Python
+    restatement above, which raises the reference's exception."""
+    from ._lib import lib
     dur_min = hparams.filter_length / hparams.sampling_rate / 2
     duration_preds[duration_preds < dur_min] = 0.0
-    rows = duration_preds.detach().cpu().tolist()  # one D2H copy instead of one .item() per symbol
-    out = torch.zeros(duration_preds.shape, dtype=torch.long)
-    for b, row in enumerate(rows):
-        end_prev, idx, spans = 0.0, [], []
-        for s, d in enumerate(row):
-            if d != 0.0:
-                idx.append(s)
-                spans.append([end_prev, end_prev + d])
-                end_prev += d
-        ints = duration_to_integer(spans, hparams)
-        out[b, idx] = torch.tensor(ints, dtype=torch.long)  # shape mismatch raises, as the reference's index assignment does
-    return duration_preds, out.to(duration_preds.device)
+    host = duration_preds.detach().to(dtype=torch.float32, device='cpu').contiguous()     # the one D2H copy (+ sync) of the conversion
+    B, L = host.shape
+    out = torch.empty(B, L, dtype=torch.long)
+    totals = torch.empty(B, dtype=torch.long)
+    status = torch.empty(B, dtype=torch.int32)
+    lib().dx_int_durations(host.data_ptr(), B, L, int(hparams.sampling_rate), int(hparams.filter_length), int(hparams.hop_length),
+                           int(bool(hparams.centered)), out.data_ptr(), totals.data_ptr(), status.data_ptr())
+    if bool(status.any()):
+        for b in torch.nonzero(status).flatten().tolist():
+            idx, ints = _row_to_integer(host[b].tolist(), hparams)       # raises IndexError / ValueError like the reference ...
+            out[b, idx] = torch.tensor(ints, dtype=torch.long)           # ... or RuntimeError (shape mismatch) here
+            totals[b] = out[b].sum()
+    out_dev = out.to(duration_preds.device, non_blocking=True)
+    return (duration_preds, out_dev, totals.tolist()) if return_totals else (duration_preds, out_dev)

@@ -23,6 +23,7 @@ from __future__ import annotations
 import torch
 
 from . import ops
+from .durations import get_int_durations
 from .functional import Lengths
 
 L_STEP, T_STEP = 16, 64
@@ -45,7 +46,7 @@ class GraphedSynthesizer:
         symbols, dur_factors, energy_factors, pitch_factors, input_lengths, speaker_ids = inputs
         m = self.model
         duration_preds = external_prosody['duration_preds'] * dur_factors
-        duration_preds, durations_int = m.get_int_durations(duration_preds, self.hparams)
+        duration_preds, durations_int, totals = get_int_durations(duration_preds, self.hparams, return_totals=True)   # host library, C
         energy = external_prosody['energy_preds'] * energy_factors
         pitch = external_prosody['pitch_preds']
         energy[durations_int == 0] = 0.0
@@ -56,9 +57,8 @@ class GraphedSynthesizer:
             pitch = m.pitch_multiply(pitch, pitch_factors)
         else:
             raise NotImplementedError
-        totals = durations_int.sum(dim=1).tolist()
         out_host = [max(1, t) for t in totals]
-        return dict(symbols=symbols, in_lens=input_lengths, in_host=input_lengths.tolist(), dur=duration_preds, dur_int=durations_int,
+        return dict(symbols=symbols, in_lens=input_lengths, dur=duration_preds, dur_int=durations_int,
                     energy=energy, pitch=pitch, out_host=out_host, n_frames=max(totals))
 
     # -- device side -----------------------------------------------------------------------------------------------------
@@ -93,7 +93,7 @@ class GraphedSynthesizer:
                     spk_embs=external_embeddings.contiguous(), accent_emb=external_accent_emb.contiguous())
         with torch.no_grad():
             if not use_graph:
-                mel, weights = self._device_forward({**live, 'in_host': prep['in_host'], 'out_host': prep['out_host'], 'n_frames': T})
+                mel, weights = self._device_forward({**live, 'in_host': prep['in_lens'].tolist(), 'out_host': prep['out_host'], 'n_frames': T})
             else:
                 Lb, Tb = _up(L, L_STEP), _up(max(T, 1), T_STEP)
                 key = (B, Lb, Tb, self.model.runtime.precision)
