@@ -87,6 +87,7 @@ def main():
     ap.add_argument('--config', default='C2', choices=['C1', 'C2', 'C5'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--launch-dump', default='', help='write one JSON line per launch of the last (eager, event-bracketed) timed step')
     ap.add_argument('--kernel-table', default='', help='write the per-kernel roofline table of the last timed step to this JSON file')
     ap.add_argument('--no-graph', action='store_true', help='issue every launch from Python instead of replaying the two captured HIP graphs')
     ap.add_argument('--no-dropout', action='store_true', help='diagnostic only: the headline metric is measured with dropout on')
@@ -219,6 +220,12 @@ def main():
                             'avg_us': v['avg_us'], 'algorithmic_bytes_per_launch': v['algorithmic_bytes_per_launch'],
                             'share_of_step': round(v['total_us'] / step_us, 3)}
                         for k, v in table.items() if v['bound'] == 'hbm' and 'achieved' in v and v['total_us'] / step_us >= 0.002}
+        if args.launch_dump:                                          # every launch of the eager step in issue order: entry point, shape arguments, us
+            keep = ('B', 'N', 'Cin', 'Cout', 'taps', 'F', 'C', 'L', 'T', 'D', 'H', 'transpose', 'accumulate', 'njobs', 'rows', 'n')
+            with open(args.launch_dump, 'w') as f:
+                for name, a, e0, e1 in records:
+                    f.write(json.dumps({'entry': name, 'label': profiling.price(name, a, geom)[0], 'us': round(1e3 * e0.elapsed_time(e1), 2),
+                                        **{k: a[k] for k in keep if k in a and isinstance(a[k], (int, float))}}) + '\n')
         if args.kernel_table:
             with open(args.kernel_table, 'w') as f:
                 json.dump({'precision': args.precision, 'config': args.config, 'ms_per_step': 1e3 * elapsed / args.steps, 'kernels': table}, f, indent=1)

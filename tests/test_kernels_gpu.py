@@ -64,6 +64,52 @@ def test_conv_gemm_forward_dgrad_wgrad(ops, precision, tol, B, N, Cin, Cout, tap
         ops.set_precision('f32')
 
 
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+@pytest.mark.parametrize('taps', [1, 3])
+def test_batched_weight_gradients_equal_single_launches(ops, precision, taps):
+    """dx_conv_wgrad_batched: queued layers of different shapes / lengths / halo rules in one launch == one dx_conv_wgrad launch per
+    layer (same kernel, other token split: equal up to fp32 summation order) and == the torch reference within the mode's tolerance."""
+    ops.set_precision(precision)
+    try:
+        h16 = {'bf16': torch.bfloat16, 'fp16': torch.float16}[precision]
+        rt = ops.DEFAULT
+        geo = [(3, 200, 128, 1024, [200, 131, 64], 1), (3, 200, 1024, 128, [200, 131, 64], 0), (2, 333, 128, 384, [333, 17], 0),
+               (3, 200, 128, 128, [200, 131, 64], -1), (2, 90, 256, 136, [90, 90], 0)]
+        jobs = []
+        for i, (B, N, Cin, Cout, lens, halo) in enumerate(geo):
+            w = randn(*((Cout, Cin, 3) if taps == 3 else (Cout, Cin)), seed=10 + i, scale=0.05)
+            pack = ops.PackedWeight(w)
+            x = randn(B, N, Cin, seed=20 + i).to(h16)
+            dy = randn(B, N, Cout, seed=30 + i).to(h16)
+            L = lens_tensor(lens)
+            if halo >= 0:                                  # the contract of skip_halo: rows beyond len + halo are zero (whole chunks of them are skipped)
+                for b, n in enumerate(lens):
+                    dy[b, n + halo:] = 0
+            ref_w, ref_b = ops.conv_wgrad(dy, x, pack, L if halo >= 0 else None, halo)
+            jobs.append((dy, x, pack, L if halo >= 0 else None, halo, ref_w, ref_b))
+        rt.defer_wgrad = True
+        sinks = []
+        for dy, x, pack, L, halo, _, _ in jobs:
+            gw, gb = torch.zeros_like(pack.weight), torch.zeros(pack.cout, device=DEV)
+            assert ops.conv_wgrad(dy, x, pack, L, halo, w_sink=gw, b_sink=gb, defer=True) == (None, None)
+            sinks.append((gw, gb))
+        assert all(float(gw.abs().max()) == 0.0 for gw, _ in sinks)                     # nothing launched yet
+        assert ops.flush_wgrads(rt) == 1 and not rt.wgrad_queue
+        for (dy, x, pack, L, halo, ref_w, ref_b), (gw, gb) in zip(jobs, sinks):
+            assert rel_err(gw, ref_w) < 2e-5 and rel_err(gb, ref_b) < 2e-5, (pack.cin, pack.cout)
+        # and against fp32 torch on the same 16-bit-rounded operands (first job)
+        dy, x, pack, L, halo, ref_w, ref_b = jobs[0]
+        xf = x.float().requires_grad_(False)
+        dyf = dy.float().clone()
+        wr = pack.weight.detach().clone().requires_grad_(True)
+        ref_conv(xf, wr, None, taps).backward(dyf)
+        assert rel_err(sinks[0][0], wr.grad) < 1e-4
+    finally:
+        ops.DEFAULT.defer_wgrad = False
+        ops.DEFAULT.wgrad_queue.clear()
+        ops.set_precision('f32')
+
+
 def test_conv_gemm_epilogues(ops):
     B, N, Cin, Cout = 2, 70, 128, 256
     w = randn(Cout, Cin, 3, seed=1, scale=0.05)

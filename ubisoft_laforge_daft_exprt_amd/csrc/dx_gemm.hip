@@ -1115,6 +1115,21 @@ struct WgradBf16Args {
   float* dbias;
 };
 
+// Up to WG_MAX_JOBS weight gradients of one kind (same taps, same operand storage) in ONE launch: blockIdx.y = job.  A single 128 -> 1024
+// k = 3 layer is 22 GFLOP (9 us of MFMA time) for a 1.5 MB result: filling 256 CUs with ONE layer needs a 16-way token split, i.e. 25 MB
+// of fp32 atomics per layer (~19 us at the memory-side atomic rate) and 128 x 64 tiles that each stage their own dY copy.  Eight layers
+// per launch fill the chip with the wide (128 x 128, one workgroup per CU) tile at a 4-way split: a quarter of the atomics and half the
+// staging per MFMA.  The descriptors travel as kernel arguments (no device-side descriptor table to keep alive or to copy).
+constexpr int WG_MAX_JOBS = 8;
+struct WgradJobDev {
+  const void* dY; const void* X; float* G; float* dbias; const int* lens;
+  int ldy, ldx, B, N, Cin, Cout, skip_halo, pad_;
+};
+struct WgradBatchArgs {
+  WgradJobDev job[WG_MAX_JOBS];
+  int ksplit;
+};
+
 __device__ __forceinline__ bf16x8 tr_fragment(const dx_h16* tile, int row0, int col0, int lane) {
   // rows row0 + 8g + [0,8), columns col0 + [0,16): lane (r = lane & 15, g = lane >> 4) gets column r, rows 8g..8g+7
   const int li = lane & 15, g = lane >> 4, q = li >> 2, p = li & 3;
@@ -1132,7 +1147,14 @@ __device__ __forceinline__ bf16x8 tr_fragment(const dx_h16* tile, int row0, int 
 // with one (65-90 k, then idle), and two co-resident workgroups gain only 13 % over one (each stages its own copy of the same dY
 // tile).  The wide form puts the same two waves per SIMD on every CU with ONE dY tile per chunk: half the staging per MFMA.
 template <int TAPS, bool DYH, bool XH, int CIW>
-__global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel(const WgradBf16Args a) {
+__global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel(const WgradBatchArgs ba) {
+  WgradBf16Args a;
+  {
+    const WgradJobDev& j = ba.job[blockIdx.y];              // kernel-argument memory, wave-uniform index: scalar loads
+    a.dY = j.dY; a.ldy = j.ldy; a.dy_bf16 = DYH; a.X = j.X; a.ldx = j.ldx; a.x_bf16 = XH; a.G = j.G;
+    a.B = j.B; a.N = j.N; a.Cin = j.Cin; a.Cout = j.Cout; a.ksplit = ba.ksplit; a.lens = j.lens; a.skip_halo = j.skip_halo; a.dbias = j.dbias;
+  }
+  if ((int)blockIdx.x >= ((a.Cout + TILE - 1) / TILE) * ((a.Cin + CIW * 32 - 1) / (CIW * 32))) return;   // a job with fewer tiles than the widest
   // wave: 64 co x 32 ci -> 4 x 2 x TAPS MFMA tiles; waves = 2 (co) x CIW (ci).
   // The dY tile and the (halo-extended) X tile are staged once per 64-token chunk and shared by the taps.
   constexpr int PAD = (TAPS - 1) / 2;
@@ -1622,7 +1644,9 @@ int dx_conv_wgrad(const void* dY, int ldy, const void* X, int ldx, float* G,
     static const int target_wide = getenv("DX_WGRAD_BLOCKS_WIDE") ? atoi(getenv("DX_WGRAD_BLOCKS_WIDE")) : 256;   // one per CU
     static const int target_k1 = getenv("DX_WGRAD_BLOCKS_K1") ? atoi(getenv("DX_WGRAD_BLOCKS_K1")) : 192;
     const int ksplit = std::max(1, std::min(total_chunks, dx_cdiv(wide ? target_wide : (taps == 1 ? target_k1 : target_blocks), tiles)));
-    WgradBf16Args a{dY, ldy, dy_bf16, X, ldx, x_bf16, G, B, N, Cin, Cout, ksplit, lens, skip_halo, dbias};
+    WgradBatchArgs a{};
+    a.job[0] = WgradJobDev{dY, X, G, dbias, lens, ldy, ldx, B, N, Cin, Cout, skip_halo, 0};
+    a.ksplit = ksplit;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(tiles, 1, ksplit);
     dx_prof_begin(DX_PROF_WGRAD_GEMM, s);
@@ -1652,6 +1676,49 @@ int dx_conv_wgrad(const void* dY, int ldy, const void* X, int ldx, float* G,
   else           hipLaunchKernelGGL(wgrad_kernel<1>, dim3(tiles, taps, ksplit), dim3(256), 0, s, a);
   dx_prof_end(DX_PROF_WGRAD_GEMM, s);
   DX_LAUNCH_CHECK("dx_conv_wgrad");
+  return DX_OK;
+}
+
+// Several weight gradients of one kind in ONE launch (see WgradBatchArgs): bf16 operand mode, every job with Cin % 128 == 0 (the wide
+// tile), same taps and the same operand storage; B, N, lens, channels, leading dimensions and the halo rule are per job.
+struct DxWgradJob {       // mirrors include/daft_exprt_hip.h
+  const void* dY; const void* X; float* G; float* dbias; const int* lens;
+  int ldy, ldx, B, N, Cin, Cout, skip_halo, reserved;
+};
+int dx_conv_wgrad_batched(const void* jobs_, int njobs, int taps, int dy_bf16, int x_bf16, void* stream) {
+  const DxWgradJob* jobs = reinterpret_cast<const DxWgradJob*>(jobs_);
+  DX_REQUIRE(jobs && njobs > 0 && njobs <= WG_MAX_JOBS, "dx_conv_wgrad_batched: 1..%d jobs per launch (got %d)", WG_MAX_JOBS, njobs);
+  DX_REQUIRE(taps == 1 || taps == 3, "dx_conv_wgrad_batched: taps must be 1 or 3");
+  WgradBatchArgs a{};
+  int tiles = 0, tile_jobs = 0, min_chunks = 0x7fffffff;
+  for (int i = 0; i < njobs; ++i) {
+    const DxWgradJob& j = jobs[i];
+    DX_REQUIRE(j.dY && j.X && j.G, "dx_conv_wgrad_batched: job %d: null pointer", i);
+    DX_REQUIRE(j.B > 0 && j.N > 0 && j.Cin > 0 && j.Cout > 0, "dx_conv_wgrad_batched: job %d: bad dims", i);
+    DX_REQUIRE((j.Cin % 128) == 0 && (j.Cout % 8) == 0 && (j.ldx % 8) == 0 && (j.ldy % 8) == 0,
+               "dx_conv_wgrad_batched: job %d: Cin must be a multiple of 128, Cout / ld* of 8 (Cin=%d Cout=%d)", i, j.Cin, j.Cout);
+    DX_REQUIRE(((uintptr_t)j.X % 16) == 0 && ((uintptr_t)j.dY % 16) == 0, "dx_conv_wgrad_batched: job %d: pointers must be 16-byte aligned", i);
+    DX_REQUIRE(j.skip_halo < 0 || j.lens, "dx_conv_wgrad_batched: job %d: skip_halo needs lens", i);
+    a.job[i] = WgradJobDev{j.dY, j.X, j.G, j.dbias, j.lens, j.ldy, j.ldx, j.B, j.N, j.Cin, j.Cout, j.skip_halo, 0};
+    const int t = dx_cdiv(j.Cout, TILE) * (j.Cin / 128);
+    tiles = std::max(tiles, t);
+    tile_jobs += t;
+    min_chunks = std::min(min_chunks, j.B * dx_cdiv(j.N, wb_bk(taps, dy_bf16 != 0, x_bf16 != 0)));
+  }
+  static const int target = getenv("DX_WGRAD_BLOCKS_BATCH") ? atoi(getenv("DX_WGRAD_BLOCKS_BATCH")) : 256;     // one 512-thread workgroup per CU
+  a.ksplit = std::max(1, std::min(min_chunks, dx_cdiv(target, tile_jobs)));
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(tiles, njobs, a.ksplit);
+  dx_prof_begin(DX_PROF_WGRAD_GEMM, s);
+#define DX_WG_LAUNCH(TAPS_)                                                                                            \
+  if (dy_bf16 && x_bf16) hipLaunchKernelGGL((wgrad_bf16_kernel<TAPS_, true, true, 4>), grid, dim3(512), 0, s, a);     \
+  else if (dy_bf16) hipLaunchKernelGGL((wgrad_bf16_kernel<TAPS_, true, false, 4>), grid, dim3(512), 0, s, a);         \
+  else if (x_bf16) hipLaunchKernelGGL((wgrad_bf16_kernel<TAPS_, false, true, 4>), grid, dim3(512), 0, s, a);          \
+  else hipLaunchKernelGGL((wgrad_bf16_kernel<TAPS_, false, false, 4>), grid, dim3(512), 0, s, a);
+  if (taps == 3) { DX_WG_LAUNCH(3) } else { DX_WG_LAUNCH(1) }
+#undef DX_WG_LAUNCH
+  dx_prof_end(DX_PROF_WGRAD_GEMM, s);
+  DX_LAUNCH_CHECK("dx_conv_wgrad_batched");
   return DX_OK;
 }
 

@@ -10,6 +10,7 @@ import os
 
 import torch
 
+from . import _lib
 from ._lib import lib
 
 PRECISIONS = ('f32', 'bf16', 'fp16')
@@ -30,6 +31,8 @@ class Runtime:
         self.arena = None            # ZeroArena of the running training step (trainer.Trainer): one zero fill for all small accumulators
         self.arena_hint = 1 << 20    # floats; tracks the high-water mark of the previous steps
         self.seed_offset = None      # device int64 scalar added to every dropout seed on the device (graph replays bump it)
+        self.defer_wgrad = False     # trainer.Trainer: the FFT blocks' weight gradients are queued and launched 8 layers at a time
+        self.wgrad_queue = {}        # (taps, dy 16-bit, x 16-bit, precision) -> [(job fields, tensors kept alive)]; see flush_wgrads
         self._packs = []             # weak refs to this runtime's PackedWeight objects (one-launch batched re-pack)
         self._tables = {}
 
@@ -346,7 +349,7 @@ def _zeros(arena, *shape, device=None):
     return arena.take(*shape) if arena is not None else torch.zeros(*shape, dtype=torch.float32, device=device)
 
 
-def conv_wgrad(dy, x, pack: PackedWeight, lens=None, halo=-1, bias=True, arena=None, w_sink=None, b_sink=None, prec=None):
+def conv_wgrad(dy, x, pack: PackedWeight, lens=None, halo=-1, bias=True, arena=None, w_sink=None, b_sink=None, prec=None, defer=False):
     """(dW, db): gradient w.r.t. the (Cout, Cin[, taps]) parameter in its own layout, and the bias gradient (column sums of
     dY, accumulated by the same launch).  ``w_sink`` / ``b_sink``: pre-zeroed ``.grad`` tensors to accumulate into directly
     (the corresponding return value is then None)."""
@@ -357,9 +360,43 @@ def conv_wgrad(dy, x, pack: PackedWeight, lens=None, halo=-1, bias=True, arena=N
     _log(pack, ('wgrad', B_ * N_, N_, pack.cin, pack.cout, pack.taps))
     prec = prec or pack.rt.precision
     _check_h16(prec, dy, x)
+    rt = pack.rt
+    if (defer and rt.defer_wgrad and w_sink is not None and (b_sink is not None or not bias) and _half(prec) and pack.cin % 128 == 0
+            and pack.cout % 8 == 0 and _rows(dy) % 8 == 0 and _rows(x) % 8 == 0):
+        # queued: launched with up to 7 other layers of the same kind by flush_wgrads (the trainer flushes at the end of every backward phase)
+        key = (pack.taps, _is_bf16(dy), _is_bf16(x), prec)
+        rt.wgrad_queue.setdefault(key, []).append(((_p(dy), _p(x), _p(g), _p(db), _p(lens), _rows(dy), _rows(x), B_, N_, pack.cin, pack.cout,
+                                                    int(halo), 0), (dy, x, g, db, lens)))
+        return None, None
     _fn('dx_conv_wgrad', prec)(_p(dy), _rows(dy), _p(x), _rows(x), _p(g), B_, N_, pack.cin, pack.cout, pack.taps, _p(lens), int(halo),
                                _half(prec), _is_bf16(dy), _is_bf16(x), _p(db), _stream())
     return (None if w_sink is not None else g), (None if b_sink is not None else db)
+
+
+class _WgradJob(ctypes.Structure):          # DxWgradJob of include/daft_exprt_hip.h
+    _fields_ = [(n, ctypes.c_void_p) for n in ('dY', 'X', 'G', 'dbias', 'lens')] + \
+               [(n, ctypes.c_int) for n in ('ldy', 'ldx', 'B', 'N', 'Cin', 'Cout', 'skip_halo', 'reserved')]
+
+
+WGRAD_BATCH = 8
+WGRAD_BATCH_LOG = {}
+
+
+def flush_wgrads(rt) -> int:
+    """Launches the weight gradients queued on ``rt`` (conv_wgrad(defer=True)): per kind, up to 8 layers per launch
+    (dx_conv_wgrad_batched).  Returns the number of launches.  Must run on the stream the producers ran on, before anything reads
+    the gradients (the gradient exchange, the optimiser)."""
+    launches = 0
+    for (taps, dyh, xh, prec), jobs in rt.wgrad_queue.items():
+        for i in range(0, len(jobs), WGRAD_BATCH):
+            part = jobs[i:i + WGRAD_BATCH]
+            arr = (_WgradJob * len(part))(*[_WgradJob(*fields) for fields, _ in part])
+            if _lib.TIMER is not None:       # diagnostic pricing of the launch (profiling.price): descriptors by array address
+                WGRAD_BATCH_LOG[ctypes.addressof(arr)] = (arr, [fields for fields, _ in part])
+            _fn('dx_conv_wgrad_batched', prec)(ctypes.addressof(arr), len(part), taps, dyh, xh, _stream())
+            launches += 1
+    rt.wgrad_queue.clear()
+    return launches
 
 
 def colsum(x, C=None):

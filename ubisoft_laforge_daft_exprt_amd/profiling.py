@@ -69,6 +69,15 @@ def price(name, a, geom: Geometry):
         byt = rows * (a['Cout'] * (2 if a['dy_bf16'] else 4) + a['Cin'] * (2 if a['x_bf16'] else 4)) + a['taps'] * a['Cin'] * a['Cout'] * 4
         label = f"wgrad_bf16_kernel<{a['taps']}>" if a['bf16'] and a['Cin'] % 8 == 0 and a['Cout'] % 8 == 0 else f"wgrad_kernel<{a['taps']}>"
         return label, 'mfma', 2.0 * a['taps'] * a['Cin'] * a['Cout'] * rows, byt
+    if name == 'dx_conv_wgrad_batched':
+        from . import ops
+        jobs = ops.WGRAD_BATCH_LOG.get(a['jobs'], (None, []))[1]       # the descriptors of this launch (kept while a timer is installed)
+        flops = byt = 0
+        for (_dy, _x, _g, _db, lens, _ldy, _ldx, B, N, Cin, Cout, _halo, _r) in jobs:
+            rows = geom.rows(B, N, lens is not None)
+            flops += 2.0 * a['taps'] * Cin * Cout * rows
+            byt += rows * (Cout * (2 if a['dy_bf16'] else 4) + Cin * (2 if a['x_bf16'] else 4)) + a['taps'] * Cin * Cout * 4
+        return f"wgrad_bf16_kernel<{a['taps']}> batched", 'mfma', (flops or None), (byt or None)
     if name in ('dx_attention_fwd', 'dx_attention_bwd'):
         rows, pairs = geom.rows(a['B'], a['N']), geom.pairs(a['B'], a['N'])
         D, H = a['D'], a['H']

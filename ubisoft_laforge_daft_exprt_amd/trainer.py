@@ -30,6 +30,7 @@ optimiser layout.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -55,6 +56,9 @@ class Trainer:
         self.device = next(model.parameters()).device
         self.reducer = GradientReducer(model, bucket_mb=bucket_mb, process_group=process_group, grad_sink=grad_sink, group_of=_group_of)
         self.use_graphs, self.max_graphs = bool(use_graphs), int(max_graphs)
+        # the FFT blocks' weight gradients go straight into the buckets (sink) and have no consumer before the exchange, so they are
+        # queued during backward and launched 8 layers at a time (ops.flush_wgrads, after every backward phase below)
+        model.runtime.defer_wgrad = bool(grad_sink) and os.environ.get('DX_DEFER_WGRAD', '1') != '0'
         # fp16 operand mode: gradients that live in 16-bit tensors (dqkv, the 1024-wide hidden gradients) would underflow; the
         # backward runs on loss * loss_scale and the fused Adam multiplies by 1 / loss_scale (static scale; bf16 needs none)
         self._fp16_loss_scale = float(getattr(hparams, 'loss_scale', 4096.0))
@@ -99,6 +103,7 @@ class Trainer:
             loss, indiv = self._forward_loss(inputs, targets, iteration)
             with red.accumulate(sync=False):                 # the exchange is launched explicitly, group by group
                 (loss * (self.loss_scale / k)).backward()
+            ops.flush_wgrads(model.runtime)                  # the FFT blocks' queued weight gradients, 8 layers per launch
             part = loss.detach() / k if k != 1 else loss.detach()
             tot = part if tot is None else tot + part
             terms.append(indiv)
@@ -109,6 +114,7 @@ class Trainer:
             for emb, leaf in cuts:
                 with red.accumulate(sync=False):
                     emb.backward(leaf.grad)
+                ops.flush_wgrads(model.runtime)
             ops.end_step_arena(model.runtime)
             ops.end_step_arena(self.criterion.runtime)
             launch(1)
