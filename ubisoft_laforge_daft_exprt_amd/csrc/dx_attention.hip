@@ -484,8 +484,12 @@ __device__ __forceinline__ void store4(dx_h16* p, float a, float b, float c, flo
   *reinterpret_cast<bf16x4*>(p) = h;
 }
 #define DX_MFMA_BF16(A, B, C) DX_MFMA_H16((A), (B), (C))
+// (fmaxf() makes hipcc canonicalise every operand first - a v_max_f32 x, x, x each, 16 per key tile.  An inline-asm v_max3_f32 on the
+// MFMA results avoids that but is WRONG: the compiler's hazard recogniser does not look inside inline asm, so the asm read the
+// accumulators before the matrix pipe had written them - maxima of stale data, a 0.4 % output error that the eager-vs-graph
+// bitwise test caught.  Inline asm may only consume values that an ordinary VALU instruction produced.)
 
-template <typename QT>
+template <typename QT, typename CT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a_) {
   AttnArgs a = a_;
   if (a.seed_offset) a.seed += *a.seed_offset;
@@ -497,11 +501,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a_
   const int len = a.lens[b];
   const QT* base = reinterpret_cast<const QT*>(a.qkv) + (size_t)b * a.N * a.ld;
   const int qrow = q0 + wave * 16 + r;
-  float* out = a.ctx + ((size_t)b * a.N + qrow) * a.ldc + h * HD;
+  CT* out = reinterpret_cast<CT*>(a.ctx) + ((size_t)b * a.N + qrow) * a.ldc + h * HD;
   if (q0 >= len) {
     if (qrow < a.N) {
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<float4*>(out + dt * 16 + g * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int dt = 0; dt < 4; ++dt) store4(out + dt * 16 + g * 4, 0.f, 0.f, 0.f, 0.f);
       if (g == 0) a.lse[((size_t)b * a.H + h) * a.N + qrow] = 0.f;
     }
     return;
@@ -516,6 +520,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a_
   float m_run = -INFINITY, l_run = 0.f;
   const int bh = b * a.H + h;
   const int ntiles = (len + 63) / 64;
+  // dropout draw index of (query row, 4 consecutive keys) = drop_index(..) >> 2: the row part is fixed per lane
+  const uint64_t drow = (uint64_t)((size_t)bh * a.N + qrow) << 14;
+  const uint32_t thresh_v = a.thresh;
   f32x4 kreg[4], vreg[4];
   DX_TILE_LOAD(QT, kreg, base, a.ld, a.D + h * HD, 0, a.N)
   DX_TILE_LOAD(QT, vreg, base, a.ld, 2 * a.D + h * HD, 0, a.N)
@@ -548,29 +555,39 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a_
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    // the running maxima settle after the first tiles: the rescale of O and l (an exp + 17 multiplies per lane) runs only in a
+    // tile where some query of the wave saw a new maximum (wave-uniform branch)
+    const bool rescale = __builtin_amdgcn_ballot_w64(m_new > m_run) != 0;
     float ls = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      float keep[4] = {1.f, 1.f, 1.f, 1.f};
-      if (a.thresh) dx_dropout_scale4(a.seed, drop_index(bh, a.N, qrow, kbase + kt * 16 + g * 4), a.thresh, a.inv_keep, keep);
+      float pk[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float p = __builtin_amdgcn_exp2f(st[kt][e] - m_new);
-        ls += p;
-        st[kt][e] = p * keep[e];
+        pk[e] = __builtin_amdgcn_exp2f(st[kt][e] - m_new);
+        ls += pk[e];
       }
+      // dropped probabilities become 0; the 1/(1-p) factor of the kept ones is applied once to O at the end
+      if (a.thresh) dx_keep4(dx_rand64(a.seed, drow | (uint64_t)((kbase + kt * 16 + g * 4) >> 2)), thresh_v, pk, 0.f);   // pk: v_exp results
+#pragma unroll
+      for (int e = 0; e < 4; ++e) st[kt][e] = pk[e];
     }
     ls += __shfl_xor(ls, 16, 64);
     ls += __shfl_xor(ls, 32, 64);
-    l_run = l_run * alpha + ls;
+    if (rescale) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[dt][e] *= alpha;
+    }
+    l_run += ls;
     m_run = m_new;
     const bf16x8 p01 = pack_pair(st[0], st[1]), p23 = pack_pair(st[2], st[3]);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       f32x4 acc = o[dt];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] *= alpha;
       acc = DX_MFMA_BF16(tr_pair(Vs, 0 + g * 4, 16 + g * 4, dt * 16, lane), p01, acc);
       acc = DX_MFMA_BF16(tr_pair(Vs, 32 + g * 4, 48 + g * 4, dt * 16, lane), p23, acc);
       o[dt] = acc;
@@ -578,15 +595,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a_
   }
   if (qrow < a.N) {
     const bool valid = qrow < len;
-    const float inv = valid ? 1.f / l_run : 0.f;
+    const float inv = valid ? (a.thresh ? a.inv_keep : 1.f) / l_run : 0.f;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-      *reinterpret_cast<float4*>(out + dt * 16 + g * 4) = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
+    for (int dt = 0; dt < 4; ++dt) store4(out + dt * 16 + g * 4, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
     if (g == 0) a.lse[((size_t)b * a.H + h) * a.N + qrow] = valid ? m_run + __log2f(l_run) : 0.f;   // base 2 (see QSCALE2)
   }
 }
 
-template <typename QT, typename OT>
+// 8 consecutive values of a row as fp32
+__device__ __forceinline__ void load8f(const float* p, float v[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8f(const dx_h16* p, float v[8]) {
+  const bf16x8 h = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (float)h[e];
+}
+
+template <typename QT, typename OT, typename CT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdArgs a_) {
   AttnBwdArgs a = a_;
   if (a.seed_offset) a.seed += *a.seed_offset;
@@ -612,26 +639,32 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
   // delta[q] = sum_d dctx[q][d] * ctx[q][d]: the four lanes that share a query row hold its 64 head channels between them
   // (a separate launch for this cost 17 us per layer: 44 MB read again for 0.4 MB of output)
   float delta_q = 0.f;
+  // the dO operand carries the 1/(1-p) of the dropped-out probabilities (dP = dO V^T is only ever used on kept elements)
+  const float ik = a.thresh ? a.inv_keep : 1.f;
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     qf[ks] = load_row8(base + (size_t)qload * a.ld + h * HD + ks * 32 + g * 8, QSCALE2);
     const size_t o = ((size_t)b * a.N + qload) * a.ldc + h * HD + ks * 32 + g * 8;
-    const float4 g0 = *reinterpret_cast<const float4*>(a.dctx + o), g1 = *reinterpret_cast<const float4*>(a.dctx + o + 4);
-    const float4 c0 = *reinterpret_cast<const float4*>(a.ctx + o), c1 = *reinterpret_cast<const float4*>(a.ctx + o + 4);
+    float gv[8], cv[8];
+    load8f(a.dctx + o, gv);
+    load8f(reinterpret_cast<const CT*>(a.ctx) + o, cv);
     bf16x8 hg;
-    hg[0] = (dx_h16)g0.x; hg[1] = (dx_h16)g0.y; hg[2] = (dx_h16)g0.z; hg[3] = (dx_h16)g0.w;
-    hg[4] = (dx_h16)g1.x; hg[5] = (dx_h16)g1.y; hg[6] = (dx_h16)g1.z; hg[7] = (dx_h16)g1.w;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hg[e] = (dx_h16)(gv[e] * ik);
     gf[ks] = hg;
-    delta_q += (g0.x * c0.x + g0.y * c0.y) + (g0.z * c0.z + g0.w * c0.w) + (g1.x * c1.x + g1.y * c1.y) + (g1.z * c1.z + g1.w * c1.w);
+    delta_q += (gv[0] * cv[0] + gv[1] * cv[1]) + (gv[2] * cv[2] + gv[3] * cv[3]) + (gv[4] * cv[4] + gv[5] * cv[5]) + (gv[6] * cv[6] + gv[7] * cv[7]);
   }
   delta_q += __shfl_xor(delta_q, 16, 64);
   delta_q += __shfl_xor(delta_q, 32, 64);
   if (g == 0 && qrow < a.N) a.delta_out[(size_t)bh * a.N + qrow] = delta_q;
   const float lse_q = a.lse[(size_t)bh * a.N + qload];
+  const float neg_delta_q = -delta_q;
   f32x4 dq[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ntiles = (len + 63) / 64;
+  const uint64_t drow = (uint64_t)((size_t)bh * a.N + qrow) << 14;
+  const uint32_t thresh_v = a.thresh;
   f32x4 kreg[4], vreg[4];
   DX_TILE_LOAD(QT, kreg, base, a.ld, a.D + h * HD, 0, a.N)
   DX_TILE_LOAD(QT, vreg, base, a.ld, 2 * a.D + h * HD, 0, a.N)
@@ -655,8 +688,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
         s = DX_MFMA_BF16(row_frag(Ks, kt * 16 + r, ks, g), qf[ks], s);
         dp = DX_MFMA_BF16(row_frag(Vs, kt * 16 + r, ks, g), gf[ks], dp);
       }
-      float keep[4] = {1.f, 1.f, 1.f, 1.f};
-      if (a.thresh) dx_dropout_scale4(a.seed, drop_index(bh, a.N, qrow, kbase + kt * 16 + g * 4), a.thresh, a.inv_keep, keep);
+      // dP - delta on kept elements, -delta on dropped ones.  The subtraction comes first: the select is inline asm and must not be the
+      // first reader of an MFMA result (dx_common.h, hazard rule)
+      float u[4] = {dp[0] - delta_q, dp[1] - delta_q, dp[2] - delta_q, dp[3] - delta_q};
+      if (a.thresh) dx_keep4(dx_rand64(a.seed, drow | (uint64_t)((kbase + kt * 16 + g * 4) >> 2)), thresh_v, u, neg_delta_q);
       float p[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) p[e] = __builtin_amdgcn_exp2f(s[e] - lse_q);
@@ -666,7 +701,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
           if (kbase + kt * 16 + g * 4 + e >= len) p[e] = 0.f;
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s[e] = p[e] * (dp[e] * keep[e] - delta_q);   // x QSCALE: applied once to dQ at the end
+      for (int e = 0; e < 4; ++e) s[e] = p[e] * u[e];                 // x QSCALE: applied once to dQ at the end
       ds[kt] = s;
     }
     const bf16x8 d01 = pack_pair(ds[0], ds[1]), d23 = pack_pair(ds[2], ds[3]);
@@ -719,8 +754,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwd
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     kf[ks] = load_row8(base + (size_t)kload * a.ld + a.D + h * HD + ks * 32 + g * 8, QSCALE2);
-    vf[ks] = load_row8(base + (size_t)kload * a.ld + 2 * a.D + h * HD + ks * 32 + g * 8, 1.f);
+    vf[ks] = load_row8(base + (size_t)kload * a.ld + 2 * a.D + h * HD + ks * 32 + g * 8, a.thresh ? a.inv_keep : 1.f);   // carries 1/(1-p), see dQ
   }
+  // this lane's 16-bit field of a draw (key krow & 3) as a v_perm_b32 selector over {hi, lo}: two bytes, zero-extended
+  const uint32_t fsel = 0x0c0c0000u | (uint32_t)((2 * (krow & 3) + 1) << 8) | (uint32_t)(2 * (krow & 3));
+  const uint32_t thresh_v = a.thresh;
   f32x4 dk[4], dv[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -765,21 +803,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwd
         s = DX_MFMA_BF16(row_frag(Qs, qt * 16 + r, ks, g), kf[ks], s);
         dp = DX_MFMA_BF16(row_frag(Gs, qt * 16 + r, ks, g), vf[ks], dp);
       }
-      float keepv[4] = {1.f, 1.f, 1.f, 1.f};
-      if (a.thresh) {
-        const uint32_t lo0 = __builtin_amdgcn_mov_dpp(wlo[qt], 0x00, 0xF, 0xF, true), hi0 = __builtin_amdgcn_mov_dpp(whi[qt], 0x00, 0xF, 0xF, true);
-        const uint32_t lo1 = __builtin_amdgcn_mov_dpp(wlo[qt], 0x55, 0xF, 0xF, true), hi1 = __builtin_amdgcn_mov_dpp(whi[qt], 0x55, 0xF, 0xF, true);
-        const uint32_t lo2 = __builtin_amdgcn_mov_dpp(wlo[qt], 0xAA, 0xF, 0xF, true), hi2 = __builtin_amdgcn_mov_dpp(whi[qt], 0xAA, 0xF, 0xF, true);
-        const uint32_t lo3 = __builtin_amdgcn_mov_dpp(wlo[qt], 0xFF, 0xF, 0xF, true), hi3 = __builtin_amdgcn_mov_dpp(whi[qt], 0xFF, 0xF, 0xF, true);
-        const uint32_t lo[4] = {lo0, lo1, lo2, lo3}, hi[4] = {hi0, hi1, hi2, hi3};
-        const int field = krow & 3;                      // which 16 bits of the word belong to this lane's key
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const uint32_t half = (field & 2) ? hi[e] : lo[e];
-          const uint32_t bits = (half >> ((field & 1) * 16)) & 0xFFFFu;
-          keepv[e] = bits >= a.thresh ? a.inv_keep : 0.f;
-        }
-      }
       float p[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) p[e] = __builtin_amdgcn_exp2f(s[e] - lse_s[qt * 16 + g * 4 + e]);
@@ -788,12 +811,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwd
         for (int e = 0; e < 4; ++e)
           if (!key_valid || qbase + qt * 16 + g * 4 + e >= len) p[e] = 0.f;
       }
+      float pk[4] = {p[0], p[1], p[2], p[3]}, u[4], nd[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { nd[e] = -delta_s[qt * 16 + g * 4 + e]; u[e] = dp[e] + nd[e]; }   // subtract BEFORE the asm select (hazard rule)
+      if (a.thresh) {
+        const uint32_t lo0 = __builtin_amdgcn_mov_dpp(wlo[qt], 0x00, 0xF, 0xF, true), hi0 = __builtin_amdgcn_mov_dpp(whi[qt], 0x00, 0xF, 0xF, true);
+        const uint32_t lo1 = __builtin_amdgcn_mov_dpp(wlo[qt], 0x55, 0xF, 0xF, true), hi1 = __builtin_amdgcn_mov_dpp(whi[qt], 0x55, 0xF, 0xF, true);
+        const uint32_t lo2 = __builtin_amdgcn_mov_dpp(wlo[qt], 0xAA, 0xF, 0xF, true), hi2 = __builtin_amdgcn_mov_dpp(whi[qt], 0xAA, 0xF, 0xF, true);
+        const uint32_t lo3 = __builtin_amdgcn_mov_dpp(wlo[qt], 0xFF, 0xF, 0xF, true), hi3 = __builtin_amdgcn_mov_dpp(whi[qt], 0xFF, 0xF, 0xF, true);
+        const uint32_t lo[4] = {lo0, lo1, lo2, lo3}, hi[4] = {hi0, hi1, hi2, hi3};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)       // one byte-permute isolates this key's field; one compare drives both selects; 1/(1-p) rides on V and dV
+          dx_keep2(__builtin_amdgcn_perm(hi[e], lo[e], fsel), thresh_v, pk[e], u[e], nd[e]);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int ql = qt * 16 + g * 4 + e;
-        const float keep = keepv[e];
-        pd[qt][e] = p[e] * keep;
-        ds[qt][e] = p[e] * (dp[e] * keep - delta_s[ql]);                  // x QSCALE: applied once to dK at the end
+        pd[qt][e] = pk[e];
+        ds[qt][e] = p[e] * u[e];                                          // x QSCALE: applied once to dK at the end
       }
     }
     const bf16x8 p01 = pack_pair(pd[0], pd[1]), p23 = pack_pair(pd[2], pd[3]);
@@ -812,7 +846,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwd
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       store4(outk + dt * 16 + g * 4, dk[dt][0] * QSCALE, dk[dt][1] * QSCALE, dk[dt][2] * QSCALE, dk[dt][3] * QSCALE);
-      store4(outv + dt * 16 + g * 4, dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
+      const float ik = a.thresh ? a.inv_keep : 1.f;
+      store4(outv + dt * 16 + g * 4, dv[dt][0] * ik, dv[dt][1] * ik, dv[dt][2] * ik, dv[dt][3] * ik);
     }
   }
 }
@@ -832,18 +867,24 @@ int check_common(const char* who, const void* qkv, int ld, int B, int N, int H, 
 
 extern "C" {
 
-int dx_attention_fwd(const void* qkvv, int ld, const int* lens, float* ctx, int ldc, float* lse,
-                     int B, int N, int H, int D, uint64_t seed, const uint64_t* seed_offset, float p_drop, int bf16, int qkv_bf16, void* stream) {
+int dx_attention_fwd(const void* qkvv, int ld, const int* lens, void* ctxv, int ldc, float* lse,
+                     int B, int N, int H, int D, uint64_t seed, const uint64_t* seed_offset, float p_drop, int bf16, int qkv_bf16, int ctx_bf16,
+                     void* stream) {
+  float* ctx = (float*)ctxv;
   const float* qkv = (const float*)qkvv;
   if (int rc = check_common("dx_attention_fwd", qkv, ld, B, N, H, D)) return rc;
   DX_REQUIRE(!qkv_bf16 || (bf16 && (ld % 8) == 0), "dx_attention_fwd: bf16-stored qkv needs bf16 mode and ld %% 8 == 0");
   DX_REQUIRE(lens && ctx && lse && ldc >= D && (ldc % 4) == 0 && ((uintptr_t)ctx % 16) == 0, "dx_attention_fwd: bad output arguments");
+  DX_REQUIRE(!ctx_bf16 || (bf16 && (ldc % 8) == 0), "dx_attention_fwd: a 16-bit context needs the 16-bit operand mode and ldc %% 8 == 0");
   DX_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "dx_attention_fwd: dropout p out of range");
   AttnArgs a{qkv, ld, lens, ctx, ldc, lse, B, N, H, D, seed, (uint32_t)lrintf(p_drop * 65536.f), 1.f / (1.f - p_drop), seed_offset};
   hipStream_t s = (hipStream_t)stream;
   dx_prof_begin(DX_PROF_ATTN_FWD, s);
-  if (bf16 && qkv_bf16) hipLaunchKernelGGL(attn_fwd_bf16_kernel<dx_h16>, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
-  else if (bf16) hipLaunchKernelGGL(attn_fwd_bf16_kernel<float>, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
+  const dim3 grid(dx_cdiv(N, 64), H, B);
+  if (bf16 && qkv_bf16 && ctx_bf16) hipLaunchKernelGGL((attn_fwd_bf16_kernel<dx_h16, dx_h16>), grid, dim3(256), 0, s, a);
+  else if (bf16 && qkv_bf16) hipLaunchKernelGGL((attn_fwd_bf16_kernel<dx_h16, float>), grid, dim3(256), 0, s, a);
+  else if (bf16 && ctx_bf16) hipLaunchKernelGGL((attn_fwd_bf16_kernel<float, dx_h16>), grid, dim3(256), 0, s, a);
+  else if (bf16) hipLaunchKernelGGL((attn_fwd_bf16_kernel<float, float>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(attn_fwd_kernel, dim3(dx_cdiv(N, 64), H, B), dim3(256), 0, s, a);
   dx_prof_end(DX_PROF_ATTN_FWD, s);
   DX_LAUNCH_CHECK("dx_attention_fwd");
@@ -851,10 +892,11 @@ int dx_attention_fwd(const void* qkvv, int ld, const int* lens, float* ctx, int 
 }
 
 // dqkv (all three thirds, every row) from dctx; `delta` is scratch [B][H][N]
-int dx_attention_bwd(const void* qkvv, int ld, const float* ctx, const float* dctx, int ldc, const float* lse, float* delta,
+int dx_attention_bwd(const void* qkvv, int ld, const void* ctxv, const float* dctx, int ldc, const float* lse, float* delta,
                      const int* lens, void* dqkvv, int ldg, int B, int N, int H, int D, uint64_t seed, const uint64_t* seed_offset, float p_drop, int bf16,
-                     int qkv_bf16, int dqkv_bf16, void* stream) {
-  const float* qkv = (const float*)qkvv; float* dqkv = (float*)dqkvv;
+                     int qkv_bf16, int dqkv_bf16, int ctx_bf16, void* stream) {
+  const float* qkv = (const float*)qkvv; float* dqkv = (float*)dqkvv; const float* ctx = (const float*)ctxv;
+  DX_REQUIRE(!ctx_bf16 || (bf16 && (ldc % 8) == 0), "dx_attention_bwd: a 16-bit context needs the 16-bit operand mode and ldc %% 8 == 0");
   if (int rc = check_common("dx_attention_bwd", qkv, ld, B, N, H, D)) return rc;
   DX_REQUIRE(!(qkv_bf16 || dqkv_bf16) || (bf16 && (ld % 8) == 0 && (ldg % 8) == 0), "dx_attention_bwd: bf16-stored qkv/dqkv need bf16 mode and ld %% 8 == 0");
   DX_REQUIRE(ctx && dctx && lse && delta && lens && dqkv, "dx_attention_bwd: null pointer");
@@ -870,7 +912,8 @@ int dx_attention_bwd(const void* qkvv, int ld, const float* ctx, const float* dc
   if (bf16) {
     const dim3 grid(dx_cdiv(N, 64), H, B);
 #define DX_ATTN_BWD(QT_, OT_)                                                                          \
-    hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<QT_, OT_>), grid, dim3(256), 0, s, a);                 \
+    if (ctx_bf16) hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<QT_, OT_, dx_h16>), grid, dim3(256), 0, s, a);   \
+    else hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<QT_, OT_, float>), grid, dim3(256), 0, s, a);             \
     hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<QT_, OT_>), grid, dim3(256), 0, s, a);
     if (qkv_bf16 && dqkv_bf16) { DX_ATTN_BWD(dx_h16, dx_h16) }
     else if (qkv_bf16) { DX_ATTN_BWD(dx_h16, float) }

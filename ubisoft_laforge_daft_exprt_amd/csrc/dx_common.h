@@ -90,6 +90,32 @@ __device__ __forceinline__ float dx_dropout_scale(uint64_t seed, uint64_t elem, 
   uint32_t bits = (uint32_t)(r >> (16 * (elem & 3))) & 0xFFFFu;
   return bits >= thresh16 ? inv_keep : 0.0f;
 }
+// Keep/drop selection without unpacking the draw: the 16-bit field is compared IN PLACE (SDWA word select) and the value is
+// selected by the resulting mask -- one v_cmp + one v_cndmask per element instead of shift, mask, compare, select, multiply.
+// The 1/(1-p) factor is not applied here: callers fold it into an operand or an epilogue scale (it is the same for all kept elements).
+// result = (field >= thresh) ? x : alt, field = low (dx_keep_lo) or high (dx_keep_hi) half of w.  thresh < 65536.
+// HAZARD RULE: x and alt must be results of ordinary VALU instructions, never MFMA accumulators -- the compiler's hazard recogniser
+// does not look inside inline asm, and an asm that reads an accumulator too early reads stale data (callers subtract or copy first).
+__device__ __forceinline__ float dx_keep_lo(uint32_t w, uint32_t thresh, float x, float alt) {
+  float y;
+  asm("v_cmp_ge_u16_sdwa vcc, %1, %2 src0_sel:WORD_0 src1_sel:WORD_0\n\tv_cndmask_b32_e32 %0, %4, %3, vcc" : "=v"(y) : "v"(w), "v"(thresh), "v"(x), "v"(alt) : "vcc");
+  return y;
+}
+__device__ __forceinline__ float dx_keep_hi(uint32_t w, uint32_t thresh, float x, float alt) {
+  float y;
+  asm("v_cmp_ge_u16_sdwa vcc, %1, %2 src0_sel:WORD_1 src1_sel:WORD_0\n\tv_cndmask_b32_e32 %0, %4, %3, vcc" : "=v"(y) : "v"(w), "v"(thresh), "v"(x), "v"(alt) : "vcc");
+  return y;
+}
+// two values under the same decision (field already isolated in `bits`): x <- kept ? x : 0, y <- kept ? y : alt
+__device__ __forceinline__ void dx_keep2(uint32_t bits, uint32_t thresh, float& x, float& y, float alt) {
+  asm("v_cmp_ge_u32_e32 vcc, %2, %3\n\tv_cndmask_b32_e32 %0, 0, %0, vcc\n\tv_cndmask_b32_e32 %1, %4, %1, vcc" : "+v"(x), "+v"(y) : "v"(bits), "v"(thresh), "v"(alt) : "vcc");
+}
+// x[i] <- kept(i) ? x[i] : alt for the four consecutive elements of one draw
+__device__ __forceinline__ void dx_keep4(uint64_t r, uint32_t thresh, float x[4], float alt) {
+  const uint32_t lo = (uint32_t)r, hi = (uint32_t)(r >> 32);
+  x[0] = dx_keep_lo(lo, thresh, x[0], alt); x[1] = dx_keep_hi(lo, thresh, x[1], alt);
+  x[2] = dx_keep_lo(hi, thresh, x[2], alt); x[3] = dx_keep_hi(hi, thresh, x[3], alt);
+}
 // four consecutive elements (elem0 % 4 == 0)
 __device__ __forceinline__ void dx_dropout_scale4(uint64_t seed, uint64_t elem0, uint32_t thresh16, float inv_keep, float out[4]) {
   uint64_t r = dx_rand64(seed, elem0 >> 2);

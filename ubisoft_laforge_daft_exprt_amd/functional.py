@@ -160,7 +160,7 @@ class FFTBlockFn(torch.autograd.Function):
         hd = ops.hidden_dtype(prec)
         qkv = ops.conv_gemm(x, packs['in'], in_b, lens=L, halo=0, out_dtype=hd, prec=prec)   # bf16 mode: attention reads bf16 q/k/v
         so = rt.seed_offset                        # device scalar added to the seeds (graph replays), or None
-        att, lse = ops.attention_fwd(qkv, lens.i32, heads, s_attn, p_attn, prec=prec, seed_offset=so)
+        att, lse = ops.attention_fwd(qkv, lens.i32, heads, s_attn, p_attn, prec=prec, seed_offset=so, ctx_dtype=hd)   # 16-bit modes: 16-bit context
         z1 = ops.conv_gemm(att, packs['out'], out_b, lens=L, halo=0, prec=prec)
         sh = ops.gemm_shadow(prec)                 # bf16 mode: GEMM operands also exist as bf16 copies written by their producers
         ln1 = ops.ln_fwd(z1, x, ln1_w, ln1_b, None, lens.i32, seed_pre=s_ln1, p_pre=p_attn, shadow=sh, seed_offset=so, prec=prec)

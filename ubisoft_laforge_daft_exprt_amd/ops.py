@@ -407,14 +407,16 @@ def colsum(x, C=None):
     return out
 
 
-def attention_fwd(qkv, lens, heads, seed, p_drop, prec=None, seed_offset=None):
+def attention_fwd(qkv, lens, heads, seed, p_drop, prec=None, seed_offset=None, ctx_dtype=torch.float32):
+    """``ctx_dtype``: storage type of the context (the 16-bit type of the operand mode, or float32)."""
     B, N, D3 = qkv.shape
     D = D3 // 3
-    ctx = torch.empty(B, N, D, dtype=torch.float32, device=qkv.device)
+    ctx = torch.empty(B, N, D, dtype=ctx_dtype, device=qkv.device)
     lse = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device)
     prec = prec or DEFAULT.precision
+    _check_h16(prec, qkv, ctx)
     _fn('dx_attention_fwd', prec)(_p(qkv), _rows(qkv), _p(lens), _p(ctx), D, _p(lse), B, N, heads, D, seed, _p(seed_offset), float(p_drop),
-                           _half(prec), _is_bf16(qkv), _stream())
+                           _half(prec), _is_bf16(qkv), _is_bf16(ctx), _stream())
     return ctx, lse
 
 
@@ -425,7 +427,7 @@ def attention_bwd(qkv, ctx, dctx, lse, lens, heads, seed, p_drop, out_dtype=torc
     delta = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device)
     prec = prec or DEFAULT.precision
     _fn('dx_attention_bwd', prec)(_p(qkv), _rows(qkv), _p(ctx), _p(dctx), _rows(dctx), _p(lse), _p(delta), _p(lens), _p(dqkv), _rows(dqkv),
-                           B, N, heads, D, seed, _p(seed_offset), float(p_drop), _half(prec), _is_bf16(qkv), _is_bf16(dqkv),
+                           B, N, heads, D, seed, _p(seed_offset), float(p_drop), _half(prec), _is_bf16(qkv), _is_bf16(dqkv), _is_bf16(ctx),
                            _stream())
     return dqkv
 
