@@ -6,6 +6,7 @@
 //   * masked mean pooling (model.py:714), batched transposes, row L2-normalise (model.py:904), cross entropy (loss.py:85)
 // All HBM-bound: the roofline for each is bytes moved / 8 TB/s (see DESIGN.md for the per-kernel byte counts).
 #include "dx_common.h"
+#include <cstdlib>
 #include <stdlib.h>
 #include <algorithm>
 
@@ -168,8 +169,11 @@ struct LnBwdArgs {
 };
 
 // grid: (blocks per batch row, B); each block walks rows of ONE batch row so FiLM gradients reduce per b.
-template <int C, typename IO, bool FILM>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a_) {
+// WAVES = waves per block (4 or 16): every block ends in one atomic per channel on the SAME 2 C addresses (dw, dbias), all blocks finish
+// together, and same-address atomics serialise (~15 ns each: 672 four-wave blocks = a 10 us tail on a 25 us kernel).  Sixteen-wave
+// blocks keep the same number of waves in flight with a quarter of the atomic chain (the sums fold through LDS first).
+template <int C, typename IO, bool FILM, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(const LnBwdArgs a_) {
   LnBwdArgs a = a_;
   if (a.seed_offset) { const uint64_t o = *a.seed_offset; a.seed_pre += o; a.seed_post += o; }
   constexpr int E = RowVec<C>::E, LPR = RowVec<C>::LPR, RPW = RowVec<C>::RPW;
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a_) {
   const IO* const Z = reinterpret_cast<const IO*>(a.z);
   IO* const DZ = reinterpret_cast<IO*>(a.dz);
   IO* const DA = reinterpret_cast<IO*>(a.da);
-  __shared__ float red[4][C];
+  __shared__ float red[WAVES][C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane % LPR, sub = lane / LPR;
   const int b = blockIdx.y;
   const int n_begin = blockIdx.x * a.rows_per_block;
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a_) {
     wv[e] = a.w[c]; bv[e] = a.bias[c];
     if constexpr (FILM) fg[e] = a.film[(size_t)b * a.ld_film + c];
   }
-  for (int n0 = n_begin + wave * RPW; n0 < n_end; n0 += 4 * RPW) {      // wave-uniform bound
+  for (int n0 = n_begin + wave * RPW; n0 < n_end; n0 += WAVES * RPW) {      // wave-uniform bound
     const int n = n0 + sub;
     const long row = (long)b * a.N + n;
     const bool inb = n < n_end, valid = inb && n < len_b;
@@ -253,8 +257,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs a_) {
       for (int e = 0; e < E; ++e) red[wave][row_col<C>(l, e)] = vals[e];
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-      const float s = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    for (int c = threadIdx.x; c < C; c += WAVES * 64) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; w += 4) s += (red[w][c] + red[w + 1][c]) + (red[w + 2][c] + red[w + 3][c]);
       if (s != 0.f) atomicAdd(&dst[c], s);
     }
   };
@@ -587,7 +593,14 @@ int dx_ln_bwd(const void* dyv, const void* zv, const float* mean, const float* r
   DX_REQUIRE(dy && z && mean && rstd && w && bias && dz && dw && dbias, "dx_ln_bwd: null pointer");
   DX_REQUIRE(C == 128 || C == 1024, "dx_ln_bwd: C must be 128 or 1024 (got %d)", C);
   DX_REQUIRE((film == nullptr) == (dfilm == nullptr), "dx_ln_bwd: film and dfilm must come together");
-  const int rpb = 64;
+  // every block ends in one atomic per channel on the SAME 2 C addresses (dw, dbias): same-address atomics serialise (~15 ns each), so the
+  // block count is a trade between memory parallelism in the row loop and the length of that atomic chain
+  static const int rpb_env = getenv("DX_LN_BWD_RPB") ? atoi(getenv("DX_LN_BWD_RPB")) : 0;
+  static const int big_env = getenv("DX_LN_BWD_BIG") ? atoi(getenv("DX_LN_BWD_BIG")) : 1;
+  // sixteen-wave blocks for C = 128 once there are rows enough to fill the chip with them (C = 1024 would need 64 KB of LDS per block: slower).
+  // Measured at C2 (frame axis, 43 k rows): C = 128: 4 waves x 64 rows 25.4 us, 16 waves x 256 rows 23.6, 16 x 192 21.4; C = 1024: 4 x 64 94 us, 4 x 96 78
+  const bool big = big_env && C == 128 && (long)B * N >= 16384;
+  const int rpb = rpb_env > 0 ? rpb_env : (big ? 192 : (C == 1024 ? 96 : 64));
   LnBwdArgs k{dy, z, mean, rstd, w, bias, film, ld_film, lens, halo, dz, da, (dx_h16*)dg_bf16_copy, dw, dbias, dfilm, ld_dfilm, B, N, rpb, relu_mask,
               seed_pre, (uint32_t)lrintf(p_pre * 65536.f), 1.f / (1.f - p_pre),
               seed_post, (uint32_t)lrintf(p_post * 65536.f), 1.f / (1.f - p_post), seed_offset};
@@ -595,8 +608,12 @@ int dx_ln_bwd(const void* dyv, const void* zv, const float* mean, const float* r
   dim3 grid(dx_cdiv(N, rpb), B);
   dx_prof_begin(DX_PROF_ROWS, s);
 #define DX_LN_BWD(CC, IO) do { \
-    if (film) hipLaunchKernelGGL((ln_bwd_kernel<CC, IO, true>), grid, dim3(256), 0, s, k); \
-    else hipLaunchKernelGGL((ln_bwd_kernel<CC, IO, false>), grid, dim3(256), 0, s, k); } while (0)
+    if (big) { \
+      if (film) hipLaunchKernelGGL((ln_bwd_kernel<CC, IO, true, 16>), grid, dim3(1024), 0, s, k); \
+      else hipLaunchKernelGGL((ln_bwd_kernel<CC, IO, false, 16>), grid, dim3(1024), 0, s, k); \
+    } else { \
+      if (film) hipLaunchKernelGGL((ln_bwd_kernel<CC, IO, true, 4>), grid, dim3(256), 0, s, k); \
+      else hipLaunchKernelGGL((ln_bwd_kernel<CC, IO, false, 4>), grid, dim3(256), 0, s, k); } } while (0)
   if (C == 128) DX_LN_BWD(128, float);
   else if (io_bf16) DX_LN_BWD(1024, dx_h16);
   else DX_LN_BWD(1024, float);
