@@ -19,11 +19,12 @@ LABELS = [
     ('conv_dk_kernel<3>', r'conv_dk_kernel<3,'), ('conv_dk_kernel<1>', r'conv_dk_kernel<1,'),
     ('conv_ws_kernel<3>', r'conv_ws_kernel<3,'), ('conv_ws_kernel<1>', r'conv_ws_kernel<1,'),
     ('conv_gemm_kernel<bf16>', r'conv_gemm_kernel<(__bf16|__hip_bfloat16|DF16b)'), ('conv_gemm_kernel<f32>', r'conv_gemm_kernel<float'),
+    ('wgrad_bf16_kernel<3,wide>', r'wgrad_bf16_kernel<3, (true|false), (true|false), 4>'), ('wgrad_bf16_kernel<1,wide>', r'wgrad_bf16_kernel<1, (true|false), (true|false), 4>'),
     ('wgrad_bf16_kernel<3>', r'wgrad_bf16_kernel<3,'), ('wgrad_bf16_kernel<1>', r'wgrad_bf16_kernel<1,'),
     ('wgrad_kernel<3>', r'wgrad_kernel<3>'), ('wgrad_kernel<1>', r'wgrad_kernel<1>'),
     ('attn_fwd', r'attn_fwd'), ('attn_bwd (dq + dkv)', r'attn_bwd_(dq|dkv)|attn_delta'),
     ('ln_fwd_kernel<128>', r'ln_fwd_kernel<128'), ('ln_fwd_kernel<1024>', r'ln_fwd_kernel<1024'),
-    ('ln_bwd_kernel<128>', r'ln_bwd_kernel<128'), ('ln_bwd_kernel<1024>', r'ln_bwd_kernel<1024'),
+    ('ln_bwd_kernel<128>', r'ln_bwd_kernel<128'), ('ln_bwd_kernel<1024>', r'ln_bwd_kernel<1024'), ('loss_finalize', r'loss_finalize_kernel'),
     ('upsample_fwd', r'upsample_fwd_kernel'), ('upsample_bwd (dsigma + dxs)', r'upsample_(bwd|dxs)_kernel'),
     ('upsample_prep', r'upsample_prep_kernel'), ('upsample_sym_bwd', r'upsample_sym_bwd_kernel'),
     ('adam_kernel', r'adam_kernel'), ('sumsq_kernel', r'sumsq_kernel'), ('mel_stats', r'mel_stats_kernel'), ('mel_grad', r'mel_grad_kernel'),
@@ -49,7 +50,9 @@ def demangle(name):
         out = name
         if name.startswith('_Z'):
             try:
-                out = subprocess.run(['c++filt', name], capture_output=True, text=True, timeout=10).stdout.strip() or name
+                tool = '/opt/rocm/lib/llvm/bin/llvm-cxxfilt'           # knows the bf16 / fp16 manglings (DF16b, DF16_) that binutils' c++filt may not
+                tool = tool if os.path.exists(tool) else 'c++filt'
+                out = subprocess.run([tool, name], capture_output=True, text=True, timeout=10).stdout.strip() or name
             except (OSError, subprocess.SubprocessError):
                 pass
         _DEMANGLED[name] = re.sub(r'\(anonymous namespace\)::', '', out)

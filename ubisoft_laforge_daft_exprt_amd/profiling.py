@@ -67,7 +67,9 @@ def price(name, a, geom: Geometry):
     if name == 'dx_conv_wgrad':
         rows = geom.rows(a['B'], a['N'], has('lens'))
         byt = rows * (a['Cout'] * (2 if a['dy_bf16'] else 4) + a['Cin'] * (2 if a['x_bf16'] else 4)) + a['taps'] * a['Cin'] * a['Cout'] * 4
-        label = f"wgrad_bf16_kernel<{a['taps']}>" if a['bf16'] and a['Cin'] % 8 == 0 and a['Cout'] % 8 == 0 else f"wgrad_kernel<{a['taps']}>"
+        wide = a['Cin'] % 128 == 0 and -(-a['Cout'] // 128) * -(-a['Cin'] // 64) >= 64      # the library's choice of the 128 x 128 tile (dx_gemm.hip)
+        label = (f"wgrad_bf16_kernel<{a['taps']}{',wide' if wide else ''}>" if a['bf16'] and a['Cin'] % 8 == 0 and a['Cout'] % 8 == 0
+                 else f"wgrad_kernel<{a['taps']}>")
         return label, 'mfma', 2.0 * a['taps'] * a['Cin'] * a['Cout'] * rows, byt
     if name == 'dx_conv_wgrad_batched':
         from . import ops
@@ -77,7 +79,7 @@ def price(name, a, geom: Geometry):
             rows = geom.rows(B, N, lens is not None)
             flops += 2.0 * a['taps'] * Cin * Cout * rows
             byt += rows * (Cout * (2 if a['dy_bf16'] else 4) + Cin * (2 if a['x_bf16'] else 4)) + a['taps'] * Cin * Cout * 4
-        return f"wgrad_bf16_kernel<{a['taps']}> batched", 'mfma', (flops or None), (byt or None)
+        return f"wgrad_bf16_kernel<{a['taps']},wide>", 'mfma', (flops or None), (byt or None)      # batched launches use the wide tile
     if name in ('dx_attention_fwd', 'dx_attention_bwd'):
         rows, pairs = geom.rows(a['B'], a['N']), geom.pairs(a['B'], a['N'])
         D, H = a['D'], a['H']
