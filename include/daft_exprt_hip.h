@@ -120,6 +120,14 @@ int dx_ln_fwd(void* a, const void* res, const float* w, const float* bias, const
               const int* lens, int halo, void* y, float* mean, float* rstd, int B, int N, int C,
               uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, const uint64_t* seed_offset, int io_bf16, void* y_bf16_copy,
               void* stream);
+/* Out-projection + dropout + residual + LayerNorm (+ FiLM + mask) of an FFT block in ONE launch (16-bit operand modes):
+ *   z = dropout(X W^T + proj_bias) + res;  y = mask(FiLM(LayerNorm(z)))      attn.out_proj (model.py:165-186) + model.py:188-191
+ * X: 16-bit [B*N][ldx], 128 columns (the attention context); Wpack: the forward pack (dx_pack_weights) of the (128, 128) weight.
+ * z / y / mean / rstd / y_bf16_copy / film / lens / halo / seeds: exactly the arguments of dx_ln_fwd with C = 128 (z = its `a` afterwards).
+ * A 64-row tile owns whole output rows, so the projection result feeds the row statistics from LDS and never goes to HBM. */
+int dx_proj_ln_fwd(const void* X, int ldx, const void* Wpack, const float* proj_bias, float* z, const float* res, const float* w, const float* bias,
+                   const float* film, int ld_film, const int* lens, int halo, float* y, float* mean, float* rstd, int B, int N,
+                   uint64_t seed_pre, float p_pre, const uint64_t* seed_offset, void* y_bf16_copy, void* stream);
 int dx_ln_bwd(const void* dy, const void* z, const float* mean, const float* rstd, const float* w, const float* bias,
               const float* film, int ld_film, const int* lens, int halo, void* dz, void* da, float* dw, float* dbias,
               float* dfilm, int ld_dfilm, int B, int N, int C, int relu_mask,

@@ -373,6 +373,35 @@ def _attention_dropout_mask_consistency(ops, tol_f, tol_b):
     assert rel_err(dqkv, qkv_r.grad) < tol_b
 
 
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+@pytest.mark.parametrize('p_drop', [0.0, 0.2])
+def test_fused_out_projection_layernorm_equals_two_launches(ops, precision, p_drop):
+    """dx_proj_ln_fwd == dx_conv_gemm (128 -> 128) followed by dx_ln_fwd, same seeds: z / mean / rstd / y / 16-bit copy, padded rows,
+    a row count that is not a multiple of the 64-row tile, FiLM on and off."""
+    ops.set_precision(precision)
+    try:
+        h16 = ops.hidden_dtype()
+        B, N = 3, 150
+        lens = lens_tensor([150, 97, 3])
+        x = randn(B, N, 128, seed=1).to(h16)
+        w = randn(128, 128, seed=2, scale=0.09)
+        pb = randn(128, seed=3, scale=0.1)
+        res = randn(B, N, 128, seed=4)
+        lw, lb = 1 + 0.1 * randn(128, seed=5), randn(128, seed=6, scale=0.1)
+        pack = ops.PackedWeight(w)
+        for film in (None, randn(B, 256, seed=7)):
+            a = ops.conv_gemm(x, pack, pb, lens=lens, halo=0)
+            y0, m0, r0, yh0 = ops.ln_fwd(a, res, lw, lb, film, lens, seed_pre=77, p_pre=p_drop, shadow=True)
+            z1, y1, m1, r1, yh1 = ops.proj_ln_fwd(x, pack, pb, res, lw, lb, film, lens, seed_pre=77, p_pre=p_drop, shadow=True)
+            valid = (torch.arange(N, device=DEV)[None, :] < lens[:, None])
+            assert rel_err(z1[valid], a[valid]) < 1e-5              # `a` now holds z (in place)
+            assert rel_err(m1, m0) < 1e-5 and rel_err(r1, r0) < 1e-4
+            assert rel_err(y1, y0) < 1e-4 and float(y1[~valid].abs().max()) == 0.0
+            assert rel_err(yh1.float(), yh0.float()) < 1e-2
+    finally:
+        ops.set_precision('f32')
+
+
 @pytest.mark.parametrize('C', [128, 1024])
 @pytest.mark.parametrize('use_film,use_res,use_mask', [(True, True, True), (False, True, True), (False, False, False)])
 def test_layernorm_family(ops, C, use_film, use_res, use_mask):

@@ -29,6 +29,7 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     trainer.train_step([dev_batch])
     torch.cuda.synchronize()
+print(prof.key_averages(group_by_stack_n=6).table(sort_by='self_device_time_total', row_limit=45, max_name_column_width=40, max_src_column_width=110))
 rows = collections.Counter()
 times = collections.Counter()
 for ev in prof.events():

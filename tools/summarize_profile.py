@@ -18,13 +18,13 @@ LABELS = [
     ('ff_pair_kernel<fwd>', r'ff_pair_kernel<false, true>'), ('ff_pair_kernel<bwd>', r'ff_pair_kernel<true, false>'),
     ('conv_dk_kernel<3>', r'conv_dk_kernel<3,'), ('conv_dk_kernel<1>', r'conv_dk_kernel<1,'),
     ('conv_ws_kernel<3>', r'conv_ws_kernel<3,'), ('conv_ws_kernel<1>', r'conv_ws_kernel<1,'),
-    ('conv_gemm_kernel<bf16>', r'conv_gemm_kernel<(__bf16|__hip_bfloat16|DF16b)'), ('conv_gemm_kernel<f32>', r'conv_gemm_kernel<float'),
+    ('conv_gemm_kernel<bf16>', r'conv_gemm_kernel<(__bf16|__hip_bfloat16|DF16b)|conv_gemm_kernelIDF16|conv_gemm_kernel<bool'), ('conv_gemm_kernel<f32>', r'conv_gemm_kernel<float'),
     ('wgrad_bf16_kernel<3,wide>', r'wgrad_bf16_kernel<3, (true|false), (true|false), 4>'), ('wgrad_bf16_kernel<1,wide>', r'wgrad_bf16_kernel<1, (true|false), (true|false), 4>'),
     ('wgrad_bf16_kernel<3>', r'wgrad_bf16_kernel<3,'), ('wgrad_bf16_kernel<1>', r'wgrad_bf16_kernel<1,'),
     ('wgrad_kernel<3>', r'wgrad_kernel<3>'), ('wgrad_kernel<1>', r'wgrad_kernel<1>'),
     ('attn_fwd', r'attn_fwd'), ('attn_bwd (dq + dkv)', r'attn_bwd_(dq|dkv)|attn_delta'),
-    ('ln_fwd_kernel<128>', r'ln_fwd_kernel<128'), ('ln_fwd_kernel<1024>', r'ln_fwd_kernel<1024'),
-    ('ln_bwd_kernel<128>', r'ln_bwd_kernel<128'), ('ln_bwd_kernel<1024>', r'ln_bwd_kernel<1024'), ('loss_finalize', r'loss_finalize_kernel'),
+    ('ln_fwd_kernel<128>', r'ln_fwd_kernel<128'), ('ln_fwd_kernel<1024>', r'ln_fwd_kernel<1024|ln_fwd_kernelILi1024E'),
+    ('ln_bwd_kernel<128>', r'ln_bwd_kernel<128'), ('ln_bwd_kernel<1024>', r'ln_bwd_kernel<1024|ln_bwd_kernelILi1024E'), ('loss_finalize', r'loss_finalize_kernel'), ('proj_ln_fwd', r'proj_ln_fwd_kernel'),
     ('upsample_fwd', r'upsample_fwd_kernel'), ('upsample_bwd (dsigma + dxs)', r'upsample_(bwd|dxs)_kernel'),
     ('upsample_prep', r'upsample_prep_kernel'), ('upsample_sym_bwd', r'upsample_sym_bwd_kernel'),
     ('adam_kernel', r'adam_kernel'), ('sumsq_kernel', r'sumsq_kernel'), ('mel_stats', r'mel_stats_kernel'), ('mel_grad', r'mel_grad_kernel'),

@@ -88,6 +88,14 @@ template <int C> __device__ __forceinline__ float row_sum(float v) {
   return v;
 }
 
+// keep/scale factors of the lane's E elements of a row: its K groups of 4 consecutive channels are one 64-bit draw each (the same
+// values dx_dropout_scale() gives element by element, at a quarter of the hashing)
+template <int C>
+__device__ __forceinline__ void row_dropout(uint64_t seed, uint64_t row, int l, uint32_t thresh, float inv_keep, float f[RowVec<C>::E]) {
+#pragma unroll
+  for (int k = 0; k < RowVec<C>::K; ++k) dx_dropout_scale4(seed, row * C + (uint64_t)((k * RowVec<C>::LPR + l) * 4), thresh, inv_keep, f + 4 * k);
+}
+
 template <int C, typename IO>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a_) {
   LnArgs a = a_;
@@ -113,8 +121,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a_) {
     if (valid) {
       row_load<C>(A + row * C, l, z);
       if (a.thresh_pre) {
+        float f[E];
+        row_dropout<C>(a.seed_pre, (uint64_t)row, l, a.thresh_pre, a.inv_keep_pre, f);
 #pragma unroll
-        for (int e = 0; e < E; ++e) z[e] *= dx_dropout_scale(a.seed_pre, (uint64_t)row * C + row_col<C>(l, e), a.thresh_pre, a.inv_keep_pre);
+        for (int e = 0; e < E; ++e) z[e] *= f[e];
       }
       if (a.res) {
         float rv[E];
@@ -134,18 +144,146 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs a_) {
     for (int e = 0; e < E; ++e) { const float d = z[e] - mu; q += d * d; }
     const float rs = 1.0f / sqrtf(row_sum<C>(q) * (1.0f / C) + LN_EPS);
     if (inb && l == 0) { a.mean[row] = valid ? mu : 0.f; a.rstd[row] = valid ? rs : 0.f; }
-    float y[E];
+    float y[E], fpost[E];
+    if (a.thresh_post) row_dropout<C>(a.seed_post, (uint64_t)row, l, a.thresh_post, a.inv_keep_post, fpost);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int c = row_col<C>(l, e);
       float t = (z[e] - mu) * rs * wv[e] + bv[e];
-      if (a.thresh_post) t *= dx_dropout_scale(a.seed_post, (uint64_t)row * C + c, a.thresh_post, a.inv_keep_post);
+      if (a.thresh_post) t *= fpost[e];
       if (a.film) t = a.film[(size_t)b * a.ld_film + c] * t + a.film[(size_t)b * a.ld_film + C + c];
       y[e] = valid ? t : 0.f;
     }
     if (inb) {
       row_store<C>(Y + row * C, l, y);
       if constexpr (sizeof(IO) == 4 && C < 256) { if (a.y_h) row_store<C>(a.y_h + row * C, l, y); }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Out-projection + dropout + residual + LayerNorm (+ FiLM + mask) in ONE launch (16-bit operand modes):
+//   a = X W^T + proj_bias   (X: 16-bit [rows][128], W: 128 x 128 as the fragment-major forward pack)   then exactly ln_fwd_kernel<128>.
+// A 64-row tile owns whole rows of the 128-wide output, so the GEMM result goes through LDS (XOR-swizzled 16-byte slots) straight
+// into the row-wise LayerNorm pass: the projection output never makes its HBM round trip (512 B/row written + read) and one
+// launch of the pair disappears.  Replaces attn.out_proj (model.py:165-186) + model.py:188-191 per FFT block.
+// ------------------------------------------------------------------------------------------------
+struct ProjLnArgs {
+  const dx_h16* X; int ldx;
+  const dx_h16* Wp;            // fragment-major pack of the 128 x 128 weight (dx_pack_weights forward image)
+  const float* proj_bias;      // [128] or null
+  LnArgs ln;                   // ln.a receives z; ln.y / y_h / mean / rstd as in ln_fwd
+};
+
+__global__ __launch_bounds__(256, 3) void proj_ln_fwd_kernel(const ProjLnArgs p_) {
+  constexpr int C = 128;
+  LnArgs a = p_.ln;
+  if (a.seed_offset) { const uint64_t o = *a.seed_offset; a.seed_pre += o; a.seed_post += o; }
+  constexpr int E = RowVec<C>::E, LPR = RowVec<C>::LPR;
+  __shared__ __attribute__((aligned(16))) float tile[64 * C];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int l = lane % LPR, sub = lane / LPR;
+  const long rows = (long)a.B * a.N;
+  const long row0 = (long)blockIdx.x * 64;
+  // Everything the row pass needs from global memory is requested BEFORE the matrix phase (the residual rows of the lane's four steps,
+  // the LayerNorm affine): a workgroup is one short dependent chain, and with these loads behind the barrier the 5.8 k-row
+  // symbol-level launch took 24 us for 3 MB.
+  bool valid[4]; int bidx[4]; long rown[4];
+  float rv[4][E];
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const long row = row0 + wave * 16 + st * 4 + sub;
+    const bool inb = row < rows;
+    const int b = inb ? (int)(row / a.N) : 0, n = inb ? (int)(row - (long)b * a.N) : 0;
+    valid[st] = inb && (!a.lens || n < a.lens[b] + a.halo);
+    bidx[st] = b;
+    rown[st] = inb ? row : -1;
+#pragma unroll
+    for (int e = 0; e < E; ++e) rv[st][e] = 0.f;
+    if (valid[st] && a.res) row_load<C>(a.res + row * C, l, rv[st]);
+  }
+  float wv[E], bv[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) { wv[e] = a.w[row_col<C>(l, e)]; bv[e] = a.bias[row_col<C>(l, e)]; }
+  // ---- phase 1: the wave's 16 tokens x 128 output channels (W = A operand, X^T = B operand: a lane owns 4 channels of one token)
+  {
+    const long trow = row0 + wave * 16 + r;
+    const long xrow = trow < rows ? trow : rows - 1;
+    bool live = false;
+    if (trow < rows) {
+      const int b = (int)(trow / a.N), n = (int)(trow - (long)b * a.N);
+      live = !a.lens || n < a.lens[b] + a.halo;
+    }
+    if (__builtin_amdgcn_ballot_w64(live) != 0) {           // a wave whose 16 rows are all padding skips the matrix work (phase 2 zero-fills)
+      bf16x8 xb[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) xb[ks] = *reinterpret_cast<const bf16x8*>(p_.X + xrow * p_.ldx + ks * 32 + g * 8);
+      f32x4 acc[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        acc[i] = p_.proj_bias ? *reinterpret_cast<const f32x4*>(p_.proj_bias + i * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 wa[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(p_.Wp + (size_t)(i * 4 + ks) * 512 + lane * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = DX_MFMA_H16(wa[i], xb[ks], acc[i]);
+      }
+      const int tok = wave * 16 + r;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        *reinterpret_cast<f32x4*>(tile + tok * C + (((i * 4 + g) ^ (tok & 15)) << 2)) = acc[i];
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: ln_fwd_kernel<128> on the tile (4 rows per wave-instruction, 16 lanes x 2 float4 per row), the four steps unrolled
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const int lrow = wave * 16 + st * 4 + sub;
+    const long row = rown[st];
+    const bool inb = row >= 0, vld = valid[st];
+    const int b = bidx[st];
+    float z[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) z[e] = 0.f;
+    if (vld) {
+#pragma unroll
+      for (int k = 0; k < RowVec<C>::K; ++k) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(tile + lrow * C + (((k * LPR + l) ^ (lrow & 15)) << 2));
+        z[k * 4 + 0] = t[0]; z[k * 4 + 1] = t[1]; z[k * 4 + 2] = t[2]; z[k * 4 + 3] = t[3];
+      }
+      if (a.thresh_pre) {
+        float f[E];
+        row_dropout<C>(a.seed_pre, (uint64_t)row, l, a.thresh_pre, a.inv_keep_pre, f);
+#pragma unroll
+        for (int e = 0; e < E; ++e) z[e] *= f[e];
+      }
+#pragma unroll
+      for (int e = 0; e < E; ++e) z[e] += rv[st][e];
+    }
+    if (inb) row_store<C>(a.a + row * C, l, z);            // z, kept for the backward (zeros on padded rows)
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) s += z[e];
+    const float mu = row_sum<C>(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { const float d = z[e] - mu; q += d * d; }
+    const float rs = 1.0f / sqrtf(row_sum<C>(q) * (1.0f / C) + LN_EPS);
+    if (inb && l == 0) { a.mean[row] = vld ? mu : 0.f; a.rstd[row] = vld ? rs : 0.f; }
+    float y[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int c = row_col<C>(l, e);
+      float t = (z[e] - mu) * rs * wv[e] + bv[e];
+      if (a.film) t = a.film[(size_t)b * a.ld_film + c] * t + a.film[(size_t)b * a.ld_film + C + c];
+      y[e] = vld ? t : 0.f;
+    }
+    if (inb) {
+      row_store<C>(a.y + row * C, l, y);
+      if (a.y_h) row_store<C>(a.y_h + row * C, l, y);
     }
   }
 }
@@ -213,15 +351,15 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(const LnBwdArgs a_) 
       row_load<C>(Z + row * C, l, z);
       mu = a.mean[row]; rs = a.rstd[row];
     }
-    float s1 = 0.f, s2 = 0.f, g[E], xh[E];
+    float s1 = 0.f, s2 = 0.f, g[E], xh[E], fpost[E];
+    if (a.thresh_post) row_dropout<C>(a.seed_post, (uint64_t)row, l, a.thresh_post, a.inv_keep_post, fpost);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const int c = row_col<C>(l, e);
       xh[e] = (z[e] - mu) * rs;
       float ln = xh[e] * wv[e] + bv[e];                 // LayerNorm output (before post-dropout / FiLM)
       float d = dy[e];                                  // zero on padded / out-of-range rows: they add nothing below
       float post = 1.f;
-      if (a.thresh_post) post = dx_dropout_scale(a.seed_post, (uint64_t)row * C + c, a.thresh_post, a.inv_keep_post);
+      if (a.thresh_post) post = fpost[e];
       if constexpr (FILM) { gfg[e] += d * ln * post; gfb[e] += d; d *= fg[e]; }
       d *= post;                                        // gradient w.r.t. LN output
       gw[e] += d * xh[e]; gb[e] += d;
@@ -238,8 +376,10 @@ __global__ __launch_bounds__(WAVES * 64) void ln_bwd_kernel(const LnBwdArgs a_) 
     if (!inb) continue;                                 // no cross-lane traffic below this point
     row_store<C>(DZ + row * C, l, dzv);
     if ((a.da || a.dg_h) && a.thresh_pre) {
+      float f[E];
+      row_dropout<C>(a.seed_pre, (uint64_t)row, l, a.thresh_pre, a.inv_keep_pre, f);
 #pragma unroll
-      for (int e = 0; e < E; ++e) dzv[e] *= dx_dropout_scale(a.seed_pre, (uint64_t)row * C + row_col<C>(l, e), a.thresh_pre, a.inv_keep_pre);
+      for (int e = 0; e < E; ++e) dzv[e] *= f[e];
     }
     if (a.da) row_store<C>(DA + row * C, l, dzv);
     if constexpr (sizeof(IO) == 4 && C < 256) { if (a.dg_h) row_store<C>(a.dg_h + row * C, l, dzv); }
@@ -579,6 +719,27 @@ int dx_ln_fwd(void* av, const void* resv, const float* w, const float* bias, con
   else hipLaunchKernelGGL((ln_fwd_kernel<1024, float>), dim3(grid), dim3(256), 0, s, k);
   dx_prof_end(DX_PROF_ROWS, s);
   DX_LAUNCH_CHECK("dx_ln_fwd");
+  return DX_OK;
+}
+
+// z = dropout(X W^T + proj_bias) + res, y = mask(FiLM(LayerNorm(z))): the out-projection and the LayerNorm of an FFT block in one launch.
+// X: 16-bit [B*N][ldx] (128 columns), Wpack: forward pack of the (128, 128) weight; every other argument as in dx_ln_fwd (C = 128, fp32 rows).
+int dx_proj_ln_fwd(const void* X, int ldx, const void* Wpack, const float* proj_bias, float* z, const float* res, const float* w, const float* bias,
+                   const float* film, int ld_film, const int* lens, int halo, float* y, float* mean, float* rstd, int B, int N,
+                   uint64_t seed_pre, float p_pre, const uint64_t* seed_offset, void* y_bf16_copy, void* stream) {
+  DX_REQUIRE(X && Wpack && z && w && bias && y && mean && rstd, "dx_proj_ln_fwd: null pointer");
+  DX_REQUIRE(B > 0 && N > 0 && ldx >= 128 && (ldx % 8) == 0, "dx_proj_ln_fwd: bad dims");
+  DX_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)Wpack % 16) == 0 && ((uintptr_t)z % 16) == 0 && ((uintptr_t)y % 16) == 0, "dx_proj_ln_fwd: pointers must be 16-byte aligned");
+  DX_REQUIRE(p_pre >= 0.f && p_pre < 1.f, "dx_proj_ln_fwd: dropout p out of range");
+  DX_REQUIRE(!film || ld_film >= 256, "dx_proj_ln_fwd: ld_film too small");
+  ProjLnArgs k{(const dx_h16*)X, ldx, (const dx_h16*)Wpack, proj_bias,
+               LnArgs{z, res, w, bias, film, ld_film, lens, halo, y, (dx_h16*)y_bf16_copy, mean, rstd, B, N,
+                      seed_pre, (uint32_t)lrintf(p_pre * 65536.f), 1.f / (1.f - p_pre), 0, 0u, 1.f, seed_offset}};
+  hipStream_t s = (hipStream_t)stream;
+  dx_prof_begin(DX_PROF_ROWS, s);
+  hipLaunchKernelGGL(proj_ln_fwd_kernel, dim3((unsigned)(((long)B * N + 63) / 64)), dim3(256), 0, s, k);
+  dx_prof_end(DX_PROF_ROWS, s);
+  DX_LAUNCH_CHECK("dx_proj_ln_fwd");
   return DX_OK;
 }
 

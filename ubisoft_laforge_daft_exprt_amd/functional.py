@@ -161,11 +161,16 @@ class FFTBlockFn(torch.autograd.Function):
         qkv = ops.conv_gemm(x, packs['in'], in_b, lens=L, halo=0, out_dtype=hd, prec=prec)   # bf16 mode: attention reads bf16 q/k/v
         so = rt.seed_offset                        # device scalar added to the seeds (graph replays), or None
         att, lse = ops.attention_fwd(qkv, lens.i32, heads, s_attn, p_attn, prec=prec, seed_offset=so, ctx_dtype=hd)   # 16-bit modes: 16-bit context
-        z1 = ops.conv_gemm(att, packs['out'], out_b, lens=L, halo=0, prec=prec)
         sh = ops.gemm_shadow(prec)                 # bf16 mode: GEMM operands also exist as bf16 copies written by their producers
-        ln1 = ops.ln_fwd(z1, x, ln1_w, ln1_b, None, lens.i32, seed_pre=s_ln1, p_pre=p_attn, shadow=sh, seed_offset=so, prec=prec)
-        y1, mean1, rstd1 = ln1[:3]
-        y1g = ln1[3] if sh else y1                 # the copy the GEMMs read
+        if ops.proj_ln_applies(att, packs['out'], prec):   # out-projection + dropout + residual + LayerNorm: one launch, z1 straight from LDS
+            z1, y1, mean1, rstd1, *rest = ops.proj_ln_fwd(att, packs['out'], out_b, x, ln1_w, ln1_b, None, lens.i32, seed_pre=s_ln1, p_pre=p_attn,
+                                                         shadow=sh, seed_offset=so, prec=prec)
+            y1g = rest[0] if sh else y1
+        else:
+            z1 = ops.conv_gemm(att, packs['out'], out_b, lens=L, halo=0, prec=prec)
+            ln1 = ops.ln_fwd(z1, x, ln1_w, ln1_b, None, lens.i32, seed_pre=s_ln1, p_pre=p_attn, shadow=sh, seed_offset=so, prec=prec)
+            y1, mean1, rstd1 = ln1[:3]
+            y1g = ln1[3] if sh else y1             # the copy the GEMMs read
         fused = ops.ff_pair_applies(y1g, packs['c1'], packs['c2'], prec)
         if fused:      # conv1 + ReLU + conv2 in ONE launch, the 1024-wide hidden tile consumed from LDS (h is still written: weight gradients)
             z2, h = ops.ff_pair(y1g, packs['c1'], packs['c2'], c1_b, c2_b, L, prec=prec, rows_exist=lens.exist)

@@ -450,6 +450,32 @@ def ln_fwd(a, res, w, b, film, lens, *, seed_pre=0, p_pre=0.0, seed_post=0, p_po
     return (y, mean, rstd, y_h) if shadow else (y, mean, rstd)
 
 
+def proj_ln_applies(x, pack: PackedWeight, prec) -> bool:
+    """The fused out-projection + LayerNorm kernel serves the 16-bit operand modes at the FFT block's shape (128 -> 128, k = 1)."""
+    return (prec in _H16 and x.dtype == _H16[prec] and x.dim() == 3 and x.shape[2] == 128 and pack.taps == 1 and pack.cin == 128
+            and pack.cout == 128 and _PROJ_LN)
+
+
+_PROJ_LN = os.environ.get('DX_PROJ_LN', '1') != '0'
+
+
+def proj_ln_fwd(x, pack: PackedWeight, proj_bias, res, w, b, film, lens, *, seed_pre=0, p_pre=0.0, halo=0, shadow=False, seed_offset=None, prec=None):
+    """z = dropout(x W^T + proj_bias) + res; y = mask(FiLM(LN(z))) in one launch.  Returns (z, y, mean, rstd[, y_16bit])."""
+    B, N, C = x.shape
+    prec = prec or pack.rt.precision
+    _check_h16(prec, x)
+    img = pack.image(prec)
+    z = torch.empty(B, N, C, dtype=torch.float32, device=x.device)
+    y = torch.empty_like(z)
+    y_h = torch.empty(B, N, C, dtype=_H16[prec], device=x.device) if shadow else None
+    mean = torch.empty(B, N, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(B, N, dtype=torch.float32, device=x.device)
+    _log(pack, ('gemm', B * N, N, pack.cin, pack.cout, 1))
+    _fn('dx_proj_ln_fwd', prec)(_p(x), _rows(x), _p(img.fwd), _p(proj_bias), _p(z), _p(res), _p(w), _p(b), _p(film), 0 if film is None else film.stride(0),
+                                _p(lens), int(halo), _p(y), _p(mean), _p(rstd), B, N, seed_pre, float(p_pre), _p(seed_offset), _p(y_h), _stream())
+    return (z, y, mean, rstd, y_h) if shadow else (z, y, mean, rstd)
+
+
 def ln_bwd(dy, z, mean, rstd, w, b, film, lens, *, relu_mask=False, want_da=False, seed_pre=0, p_pre=0.0, seed_post=0, p_post=0.0,
            arena=None, w_sink=None, b_sink=None, halo=0, shadow=False, seed_offset=None, prec=None):
     """Returns (dz, da or None, dw, db, dfilm or None[, dg_bf16]); dw/db are None when accumulated straight into the given sinks."""

@@ -93,6 +93,10 @@ def price(name, a, geom: Geometry):
         C, ab = a['C'], (2 if a['io_bf16'] else 4)
         byt = rows * (C * (2 * ab + 4 + (4 if has('res') else 0) + (2 if has('y_bf16_copy') else 0)) + 8)
         return f'ln_fwd_kernel<{C}>', 'hbm', None, byt
+    if name == 'dx_proj_ln_fwd':                         # X (16-bit) read; z, y written, residual read (fp32); 16-bit copy of y; the 32 KB weight pack
+        rows = geom.rows(a['B'], a['N'], has('lens'))
+        byt = rows * (128 * (2 + 4 + 4 + (4 if has('res') else 0) + (2 if has('y_bf16_copy') else 0)) + 8) + 128 * 128 * 2
+        return 'proj_ln_fwd', 'hbm', None, byt
     if name == 'dx_ln_bwd':
         rows = geom.rows(a['B'], a['N'], has('lens'))
         C, zb = a['C'], (2 if a['io_bf16'] else 4)
