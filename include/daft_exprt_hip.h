@@ -97,6 +97,14 @@ int dx_unpack_wgrad(const float* G, float* grad, int Cout, int Cin, int taps, in
 int dx_ff_pair(const void* X, int ldx, const void* Wa, const void* Wb, const float* bias_a, const float* bias_b,
                const void* aux, int ld_aux, void* H, int ldh, float* Y, int ldy,
                int B, int N, int F, int relu_mid, int accumulate, const int* lens, int skip_halo, const int* rows_exist, void* stream);
+/* dx_ff_pair (forward) with the FFT block's SECOND LayerNorm folded into its epilogue (model.py:225-233 after :206-217): the output tile
+ * is normalised while it is in LDS.  Z = res + dropout(pair output) (fp32 [B][N][128], what dx_ln_fwd leaves in `a`), Yln / mean / rstd /
+ * film / seeds as in dx_ln_fwd with C = 128 and halo 0 (rows >= lens[b] are masked); lens is required; skip_halo as in dx_ff_pair (it
+ * only decides which whole tiles are computed: the hidden rows of the halo are still written to H for the weight gradients). */
+int dx_ff_pair_ln(const void* X, int ldx, const void* Wa, const void* Wb, const float* bias_a, const float* bias_b, void* H, int ldh, float* Z,
+                  int B, int N, int F, const int* lens, int skip_halo, const int* rows_exist,
+                  const float* res, const float* ln_w, const float* ln_b, const float* film, int ld_film, float* Yln, float* mean, float* rstd,
+                  uint64_t seed_pre, float p_pre, const uint64_t* seed_offset, void* stream);
 /* out[c] += sum_rows X[row][c]   (bias gradients) */
 int dx_colsum(const void* X, int ldx, float* out, long rows, int C, int x_bf16, void* stream);
 

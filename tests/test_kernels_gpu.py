@@ -375,6 +375,35 @@ def _attention_dropout_mask_consistency(ops, tol_f, tol_b):
 
 @pytest.mark.parametrize('precision', ['bf16', 'fp16'])
 @pytest.mark.parametrize('p_drop', [0.0, 0.2])
+def test_ff_pair_layernorm_epilogue_equals_two_launches(ops, precision, p_drop):
+    """dx_ff_pair_ln == dx_ff_pair followed by dx_ln_fwd (same seeds): z, statistics, y, the hidden tensor; lengths that put the last tile on
+    the halo row, on a tile edge and inside a tile; FiLM on and off."""
+    ops.set_precision(precision)
+    try:
+        h16 = ops.hidden_dtype()
+        B, N, Fc = 5, 300, 1024
+        lens = lens_tensor([300, 252, 126, 127, 40])
+        valid = (torch.arange(N, device=DEV)[None, :] < lens[:, None])
+        x = (randn(B, N, 128, seed=1) * valid[:, :, None]).to(h16)
+        w1, b1 = randn(Fc, 128, 3, seed=2, scale=1 / math.sqrt(384)), randn(Fc, seed=3, scale=0.1)
+        w2, b2 = randn(128, Fc, 3, seed=4, scale=1 / math.sqrt(3 * Fc)), randn(128, seed=5, scale=0.1)
+        res = randn(B, N, 128, seed=6)
+        lw, lb = 1 + 0.1 * randn(128, seed=7), randn(128, seed=8, scale=0.1)
+        p1, p2 = ops.PackedWeight(w1), ops.PackedWeight(w2)
+        for film in (None, randn(B, 256, seed=9)):
+            z0, h0 = ops.ff_pair(x, p1, p2, b1, b2, lens)
+            y0, m0, r0 = ops.ln_fwd(z0, res, lw, lb, film, lens, seed_pre=91, p_pre=p_drop)
+            z1, h1, y1, m1, r1 = ops.ff_pair_ln(x, p1, p2, b1, b2, lens, res, lw, lb, film, seed_pre=91, p_pre=p_drop)
+            assert torch.equal(h0, h1)
+            assert rel_err(z1[valid], z0[valid]) < 1e-6                 # z0 was overwritten with z by ln_fwd
+            assert rel_err(m1[valid], m0[valid]) < 1e-5 and rel_err(r1[valid], r0[valid]) < 1e-4
+            assert rel_err(y1, y0) < 1e-4 and float(y1[~valid].abs().max()) == 0.0
+    finally:
+        ops.set_precision('f32')
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+@pytest.mark.parametrize('p_drop', [0.0, 0.2])
 def test_fused_out_projection_layernorm_equals_two_launches(ops, precision, p_drop):
     """dx_proj_ln_fwd == dx_conv_gemm (128 -> 128) followed by dx_ln_fwd, same seeds: z / mean / rstd / y / 16-bit copy, padded rows,
     a row count that is not a multiple of the 64-row tile, FiLM on and off."""

@@ -46,6 +46,11 @@ struct FFPairArgs {
   int accumulate;
   const int* lens; int skip_halo;
   const int* rows_exist;             // optional [B]: input / hidden rows n >= rows_exist[b] do not exist (see dx_gemm.hip ConvGemmArgs)
+  // optional LayerNorm epilogue of the forward (ln_w != null): Y receives z = ln_res + dropout(conv output), ln_y = mask(FiLM(LN(z)))
+  // -- the block's second LayerNorm (model.py:225-233) done on the output tile while it is in LDS (same arithmetic as dx_ln_fwd)
+  const float* ln_res; const float* ln_w; const float* ln_b; const float* film; int ld_film;
+  float* ln_y; float* ln_mean; float* ln_rstd;
+  unsigned long long seed_pre; unsigned thresh_pre; float inv_keep_pre; const unsigned long long* seed_offset;
   unsigned long long* stamps;        // diagnostic builds (-DDX_FFPAIR_STAMPS, tools/ffpair_stamps.py) only: [workgroup][role][16] s_memtime values
 };
 
@@ -177,6 +182,7 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
       for (int u = tid; u < rows * 32; u += 512) {
         const int row = u >> 5, q = u & 31;
         *reinterpret_cast<f32x4*>(a.Y + ((size_t)b * a.N + n0 + row) * a.ldy + q * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.ln_w) *reinterpret_cast<f32x4*>(a.ln_y + ((size_t)b * a.N + n0 + row) * 128 + q * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     return;
   }
@@ -403,7 +409,55 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
   // ---- output: the consumers' 128 x 128 fp32 tile went through LDS and leaves as full 512-byte rows written by ALL eight waves
   //      (the four consumer waves alone, one 16-byte store per lane per (i, j), spent 7 k cycles on it while the producers idled)
   __syncthreads();
-  {
+  if (a.ln_w) {
+    // LayerNorm epilogue: a row of the tile = 32 consecutive lanes x 4 channels; statistics by 5 xor-shuffles inside the half wave
+    const int s = tid & 31;
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(a.ln_w + s * 4), bv = *reinterpret_cast<const f32x4*>(a.ln_b + s * 4);
+    f32x4 fg = f32x4{1.f, 1.f, 1.f, 1.f}, fb = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.film) {
+      fg = *reinterpret_cast<const f32x4*>(a.film + (size_t)b * a.ld_film + s * 4);
+      fb = *reinterpret_cast<const f32x4*>(a.film + (size_t)b * a.ld_film + 128 + s * 4);
+    }
+    const int len_b = a.lens ? a.lens[b] : a.N;
+    const unsigned long long seed = a.seed_pre + (a.seed_offset ? *a.seed_offset : 0ull);
+    f32x4 resv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                       // the residual rows of all eight passes are requested first
+      const int row = (tid >> 5) + k * 16, n = n0 + row;
+      resv[k] = (row < len_cols && n < len_b) ? *reinterpret_cast<const f32x4*>(a.ln_res + ((size_t)b * a.N + n) * 128 + s * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int row = (tid >> 5) + k * 16, n = n0 + row;
+      const bool inb = row < len_cols, valid = inb && n < len_b;
+      const size_t grow = (size_t)b * a.N + n;
+      f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (valid) {
+        z = *reinterpret_cast<const f32x4*>(stage + row * 512 + ((s ^ (row & 15)) << 4));
+        if (a.thresh_pre) {
+          float f[4];
+          dx_dropout_scale4(seed, (unsigned long long)grow * 128 + s * 4, a.thresh_pre, a.inv_keep_pre, f);
+          z[0] *= f[0]; z[1] *= f[1]; z[2] *= f[2]; z[3] *= f[3];
+        }
+        z += resv[k];
+      }
+      if (inb) *reinterpret_cast<f32x4*>(a.Y + grow * a.ldy + s * 4) = z;       // z, kept for the backward
+      float sum = (z[0] + z[1]) + (z[2] + z[3]);
+#pragma unroll
+      for (int off = 1; off < 32; off <<= 1) sum += __shfl_xor(sum, off, 64);
+      const float mu = sum * (1.0f / 128);
+      const f32x4 d = z - mu;
+      float q = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+#pragma unroll
+      for (int off = 1; off < 32; off <<= 1) q += __shfl_xor(q, off, 64);
+      const float rs = 1.0f / sqrtf(q * (1.0f / 128) + 1e-5f);
+      if (inb && s == 0) { a.ln_mean[grow] = valid ? mu : 0.f; a.ln_rstd[grow] = valid ? rs : 0.f; }
+      f32x4 y = d * rs * wv + bv;
+      if (a.film) y = fg * y + fb;
+      if (!valid) y = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (inb) *reinterpret_cast<f32x4*>(a.ln_y + grow * 128 + s * 4) = y;
+    }
+  } else {
     f32x4 old[8];
     if (a.accumulate) {
 #pragma unroll
@@ -442,10 +496,19 @@ extern "C" {
 // conv2.bwd / conv1.bwd).  H [B][N][F] bf16 receives the mid activation; Y [B][N][128] fp32 the result (+= if accumulate).
 // relu_mid: mid = ReLU.  aux (optional, bf16 [B][N][F]): mid zeroes every position where aux <= 0 (exactly one of the two).
 // skip_halo: token tiles that start at or beyond min(lens[b] + skip_halo, N) are padding nobody reads: zero-filled, not computed.
-int dx_ff_pair(const void* X, int ldx, const void* Wa, const void* Wb, const float* bias_a, const float* bias_b,
-               const void* aux, int ld_aux, void* H, int ldh, float* Y, int ldy,
-               int B, int N, int F, int relu_mid, int accumulate, const int* lens, int skip_halo, const int* rows_exist, void* stream) {
+static int ff_pair_launch(const void* X, int ldx, const void* Wa, const void* Wb, const float* bias_a, const float* bias_b,
+                          const void* aux, int ld_aux, void* H, int ldh, float* Y, int ldy,
+                          int B, int N, int F, int relu_mid, int accumulate, const int* lens, int skip_halo, const int* rows_exist,
+                          const float* ln_res, const float* ln_w, const float* ln_b, const float* film, int ld_film,
+                          float* ln_y, float* ln_mean, float* ln_rstd, unsigned long long seed_pre, float p_pre, const unsigned long long* seed_offset,
+                          void* stream) {
   DX_REQUIRE(X && Wa && Wb && H && Y, "dx_ff_pair: null pointer");
+  if (ln_w) {
+    DX_REQUIRE(relu_mid && !accumulate && lens && skip_halo >= 0 && ldy == 128, "dx_ff_pair_ln: forward pair, no accumulate, lens, dense Z");
+    DX_REQUIRE(ln_res && ln_b && ln_y && ln_mean && ln_rstd, "dx_ff_pair_ln: null pointer");
+    DX_REQUIRE(!film || ld_film >= 256, "dx_ff_pair_ln: ld_film too small");
+    DX_REQUIRE(p_pre >= 0.f && p_pre < 1.f, "dx_ff_pair_ln: dropout p out of range");
+  }
   DX_REQUIRE(B > 0 && N > 0 && F >= 128 && (F % 128) == 0, "dx_ff_pair: bad dims B=%d N=%d F=%d (F must be a multiple of 128)", B, N, F);
   DX_REQUIRE(ldx >= 128 && (ldx % 8) == 0 && ldh >= F && (ldh % 8) == 0 && ldy >= 128 && (ldy % 4) == 0, "dx_ff_pair: bad leading dimensions");
   DX_REQUIRE(!aux || (ld_aux >= F && (ld_aux % 4) == 0), "dx_ff_pair: bad ld_aux");
@@ -454,7 +517,8 @@ int dx_ff_pair(const void* X, int ldx, const void* Wa, const void* Wb, const flo
   DX_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)Wa % 16) == 0 && ((uintptr_t)Wb % 16) == 0 && ((uintptr_t)H % 16) == 0 &&
              ((uintptr_t)Y % 16) == 0 && ((uintptr_t)aux % 8) == 0, "dx_ff_pair: pointers must be 16-byte aligned");
   FFPairArgs a{(const dx_h16*)X, ldx, (const dx_h16*)Wa, (const dx_h16*)Wb, bias_a, bias_b, (const dx_h16*)aux, ld_aux,
-               (dx_h16*)H, ldh, Y, ldy, B, N, F, accumulate, lens, skip_halo, rows_exist, nullptr};
+               (dx_h16*)H, ldh, Y, ldy, B, N, F, accumulate, lens, skip_halo, rows_exist,
+               ln_res, ln_w, ln_b, film, ld_film, ln_y, ln_mean, ln_rstd, seed_pre, (unsigned)lrintf(p_pre * 65536.f), 1.f / (1.f - p_pre), seed_offset, nullptr};
 #ifdef DX_FFPAIR_STAMPS
   a.stamps = g_ffpair_stamps;
 #endif
@@ -472,6 +536,25 @@ int dx_ff_pair(const void* X, int ldx, const void* Wa, const void* Wb, const flo
   dx_prof_end(DX_PROF_CONV_GEMM, s);
   DX_LAUNCH_CHECK("dx_ff_pair");
   return DX_OK;
+}
+
+int dx_ff_pair(const void* X, int ldx, const void* Wa, const void* Wb, const float* bias_a, const float* bias_b,
+               const void* aux, int ld_aux, void* H, int ldh, float* Y, int ldy,
+               int B, int N, int F, int relu_mid, int accumulate, const int* lens, int skip_halo, const int* rows_exist, void* stream) {
+  return ff_pair_launch(X, ldx, Wa, Wb, bias_a, bias_b, aux, ld_aux, H, ldh, Y, ldy, B, N, F, relu_mid, accumulate, lens, skip_halo, rows_exist,
+                        nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0ull, 0.f, nullptr, stream);
+}
+
+// The forward pair with the block's second LayerNorm folded into its epilogue:
+//   Z = res + dropout(conv3(Wb, ReLU(conv3(Wa, X) + bias_a)) + bias_b)   (fp32 [B][N][128], kept for the backward)
+//   Yln = mask(FiLM(LayerNorm(Z)))                                         (the arguments of dx_ln_fwd with C = 128, halo 0)
+int dx_ff_pair_ln(const void* X, int ldx, const void* Wa, const void* Wb, const float* bias_a, const float* bias_b, void* H, int ldh, float* Z,
+                  int B, int N, int F, const int* lens, int skip_halo, const int* rows_exist,
+                  const float* res, const float* ln_w, const float* ln_b, const float* film, int ld_film, float* Yln, float* mean, float* rstd,
+                  uint64_t seed_pre, float p_pre, const uint64_t* seed_offset, void* stream) {
+  DX_REQUIRE(ln_w != nullptr, "dx_ff_pair_ln: null pointer");
+  return ff_pair_launch(X, ldx, Wa, Wb, bias_a, bias_b, nullptr, 0, H, ldh, Z, 128, B, N, F, 1, 0, lens, skip_halo, rows_exist,
+                        res, ln_w, ln_b, film, ld_film, Yln, mean, rstd, (unsigned long long)seed_pre, p_pre, (const unsigned long long*)seed_offset, stream);
 }
 
 }  // extern "C"

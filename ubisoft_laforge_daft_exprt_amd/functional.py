@@ -172,12 +172,17 @@ class FFTBlockFn(torch.autograd.Function):
             y1, mean1, rstd1 = ln1[:3]
             y1g = ln1[3] if sh else y1             # the copy the GEMMs read
         fused = ops.ff_pair_applies(y1g, packs['c1'], packs['c2'], prec)
-        if fused:      # conv1 + ReLU + conv2 in ONE launch, the 1024-wide hidden tile consumed from LDS (h is still written: weight gradients)
+        y2 = None
+        if fused and ops._FF_LN:   # ... and the block's second LayerNorm on the output tile while it is still in LDS
+            z2, h, y2, mean2, rstd2 = ops.ff_pair_ln(y1g, packs['c1'], packs['c2'], c1_b, c2_b, L, y1, ln2_w, ln2_b, film, seed_pre=s_ln2, p_pre=p_conv,
+                                                     seed_offset=so, prec=prec, rows_exist=lens.exist)
+        elif fused:    # conv1 + ReLU + conv2 in ONE launch, the 1024-wide hidden tile consumed from LDS (h is still written: weight gradients)
             z2, h = ops.ff_pair(y1g, packs['c1'], packs['c2'], c1_b, c2_b, L, prec=prec, rows_exist=lens.exist)
         else:
             h = ops.conv_gemm(y1g, packs['c1'], c1_b, relu=True, lens=L, halo=1, out_dtype=hd, prec=prec, rows_exist=lens.exist)   # conv2 reads one row past the end
             z2 = ops.conv_gemm(h, packs['c2'], c2_b, lens=L, halo=0, prec=prec, rows_exist=lens.exist)
-        y2, mean2, rstd2 = ops.ln_fwd(z2, y1, ln2_w, ln2_b, film, lens.i32, seed_pre=s_ln2, p_pre=p_conv, seed_offset=so, prec=prec)
+        if y2 is None:
+            y2, mean2, rstd2 = ops.ln_fwd(z2, y1, ln2_w, ln2_b, film, lens.i32, seed_pre=s_ln2, p_pre=p_conv, seed_offset=so, prec=prec)
         ctx.save_for_backward(x, film, qkv, att, lse, z1, mean1, rstd1, y1g, h, z2, mean2, rstd2, ln1_w, ln1_b, ln2_w, ln2_b)
         ctx.lens, ctx.packs, ctx.heads = lens, packs, heads
         ctx.drop = (p_attn, p_conv, s_attn, s_ln1, s_ln2)

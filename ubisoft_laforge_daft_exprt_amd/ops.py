@@ -305,6 +305,29 @@ def ff_pair(x, pack1: PackedWeight, pack2: PackedWeight, bias1, bias2, lens, *, 
     return out, h
 
 
+_FF_LN = os.environ.get('DX_FF_LN', '1') != '0'
+
+
+def ff_pair_ln(x, pack1: PackedWeight, pack2: PackedWeight, bias1, bias2, lens, res, ln_w, ln_b, film, *, seed_pre=0, p_pre=0.0, seed_offset=None,
+               halo=1, prec=None, rows_exist=None):
+    """The forward pair with the block's second LayerNorm folded into its epilogue (dx_ff_pair_ln).  Returns (z, h, y, mean, rstd):
+    z = res + dropout(pair output) [fp32, what ln_fwd leaves in its input], y = mask(FiLM(LN(z)))."""
+    prec = pack1.rt.precision if prec is None else prec
+    B, N, D = x.shape
+    Fc = pack1.cout
+    i1, i2 = pack1.image(prec), pack2.image(prec)
+    h = torch.empty(B, N, Fc, dtype=_H16[prec], device=x.device)
+    z = torch.empty(B, N, 128, dtype=torch.float32, device=x.device)
+    y = torch.empty_like(z)
+    mean = torch.empty(B, N, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(B, N, dtype=torch.float32, device=x.device)
+    _log(pack1, ('ffpair', B * N, N, 128, Fc, 3))
+    _fn('dx_ff_pair_ln', prec)(_p(x), _rows(x), _p(i1.fwd), _p(i2.fwd), _p(bias1), _p(bias2), _p(h), _rows(h), _p(z), B, N, Fc, _p(lens), int(halo),
+                               _p(rows_exist), _p(res), _p(ln_w), _p(ln_b), _p(film), 0 if film is None else film.stride(0), _p(y), _p(mean), _p(rstd),
+                               seed_pre, float(p_pre), _p(seed_offset), _stream())
+    return z, h, y, mean, rstd
+
+
 class ZeroArena:
     """One zero-filled buffer handed out in 16-byte aligned slices: the many small accumulators (atomic targets) of one
     backward call cost a single memset launch instead of one each."""

@@ -64,6 +64,11 @@ def price(name, a, geom: Geometry):
         F = a['F']
         byt = rows * (128 * 2 + F * 2 + 128 * 4 * (2 if a['accumulate'] else 1) + (F * 2 if has('aux') else 0)) + 2 * 3 * 128 * F * 2
         return 'ff_pair_kernel<bwd>' if has('aux') else 'ff_pair_kernel<fwd>', 'mfma', 2.0 * 2 * 3 * 128 * F * rows, byt
+    if name == 'dx_ff_pair_ln':                          # the forward pair + the LayerNorm epilogue: residual read, z and y written
+        rows = geom.rows(a['B'], a['N'], has('lens'))
+        F = a['F']
+        byt = rows * (128 * 2 + F * 2 + 128 * 4 * 3 + 8) + 2 * 3 * 128 * F * 2
+        return 'ff_pair_kernel<fwd>', 'mfma', 2.0 * 2 * 3 * 128 * F * rows, byt
     if name == 'dx_conv_wgrad':
         rows = geom.rows(a['B'], a['N'], has('lens'))
         byt = rows * (a['Cout'] * (2 if a['dy_bf16'] else 4) + a['Cin'] * (2 if a['x_bf16'] else 4)) + a['taps'] * a['Cin'] * a['Cout'] * 4
