@@ -112,12 +112,12 @@ int dx_colsum(const void* X, int ldx, float* out, long rows, int C, int x_bf16, 
 int dx_attention_fwd(const void* qkv, int ld, const int* lens, void* ctx, int ldc, float* lse,
                      int B, int N, int H, int D, uint64_t seed, const uint64_t* seed_offset, float p_drop, int bf16, int qkv_bf16, int ctx_bf16,
                      void* stream);
-int dx_attention_bwd(const void* qkv, int ld, const void* ctx, const float* dctx, int ldc, const float* lse, float* delta,
+int dx_attention_bwd(const void* qkv, int ld, const void* ctx, const void* dctx, int ldc, const float* lse, float* delta,
                      const int* lens, void* dqkv, int ldg, int B, int N, int H, int D, uint64_t seed, const uint64_t* seed_offset, float p_drop, int bf16,
                      int qkv_bf16, int dqkv_bf16, int ctx_bf16, void* stream);
 /* bf16 = 1: QK^T / PV (and the five backward products) on v_mfma_f32_16x16x32_bf16, softmax and accumulation in fp32;
  * qkv_bf16 / dqkv_bf16 / ctx_bf16 = 1: the in-projection output / its gradient / the attention context are stored as bf16 (ld in
- * elements; ctx and dctx share ldc).  The context is only ever consumed as a 16-bit GEMM operand (out-projection, its weight gradient)
+ * elements; ctx and dctx share ldc AND the storage type: ctx_bf16 = 1 means both are 16-bit).  The context is only ever consumed as a 16-bit GEMM operand (out-projection, its weight gradient)
  * and in delta = rowsum(dctx * ctx), so storing it in 16 bits halves four passes over it. */
 
 /* ---- dropout + residual + LayerNorm + FiLM + mask: model.py:188-191, :225-233, :256-258, :655-669 ------------------- */

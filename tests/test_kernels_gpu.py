@@ -324,7 +324,7 @@ def _attention_forward_backward(ops, B, N, lens, tol_f, tol_b):
         # 16-bit-stored context as well (the FFT block's configuration): same results within the mode's tolerance
         ctx_c, lse_c = ops.attention_fwd(qh, ln, heads, 0, 0.0, ctx_dtype=h16)
         assert ctx_c.dtype == h16 and rel_err(ctx_c.float(), ref.detach()) < tol_f and torch.equal(lse_c, lse_h)
-        dq_c = ops.attention_bwd(qh, ctx_c, dctx, lse_c, ln, heads, 0, 0.0, out_dtype=h16)
+        dq_c = ops.attention_bwd(qh, ctx_c, dctx.to(h16), lse_c, ln, heads, 0, 0.0, out_dtype=h16)       # dctx is stored like ctx
         assert rel_err(dq_c.float(), qkv.grad) < tol_b
 
 

@@ -646,7 +646,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
     qf[ks] = load_row8(base + (size_t)qload * a.ld + h * HD + ks * 32 + g * 8, QSCALE2);
     const size_t o = ((size_t)b * a.N + qload) * a.ldc + h * HD + ks * 32 + g * 8;
     float gv[8], cv[8];
-    load8f(a.dctx + o, gv);
+    load8f(reinterpret_cast<const CT*>(a.dctx) + o, gv);           // dctx is stored like ctx (both fp32, or both 16-bit)
     load8f(reinterpret_cast<const CT*>(a.ctx) + o, cv);
     bf16x8 hg;
 #pragma unroll
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
   }
 }
 
-template <typename QT, typename OT>
+template <typename QT, typename OT, typename CT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwdArgs a_) {
   AttnBwdArgs a = a_;
   if (a.seed_offset) a.seed += *a.seed_offset;
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwd
   const int r = lane & 15, g = lane >> 4;
   const int len = a.lens[b];
   const QT* base = reinterpret_cast<const QT*>(a.qkv) + (size_t)b * a.N * a.ld;
-  const float* gbase = a.dctx + (size_t)b * a.N * a.ldc;
+  const CT* gbase = reinterpret_cast<const CT*>(a.dctx) + (size_t)b * a.N * a.ldc;
   const int krow = k0 + wave * 16 + r;
   OT* outk = reinterpret_cast<OT*>(a.dqkv) + ((size_t)b * a.N + krow) * a.ldg + a.D + h * HD;
   OT* outv = reinterpret_cast<OT*>(a.dqkv) + ((size_t)b * a.N + krow) * a.ldg + 2 * a.D + h * HD;
@@ -766,18 +766,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwd
   f32x4 qreg[4], greg[4];
   float lse_r = 0.f, delta_r = 0.f;
   DX_TILE_LOAD(QT, qreg, base, a.ld, h * HD, 0, a.N)
-  DX_TILE_LOAD(float, greg, gbase, a.ldc, h * HD, 0, a.N)
+  DX_TILE_LOAD(CT, greg, gbase, a.ldc, h * HD, 0, a.N)
   if (tid < 64 && tid < a.N) { lse_r = a.lse[(size_t)bh * a.N + tid]; delta_r = a.delta[(size_t)bh * a.N + tid]; }
   for (int qt0 = 0; qt0 < ntiles; ++qt0) {
     const int qbase = qt0 * 64;
     __syncthreads();
     DX_TILE_STORE(QT, qreg, Qs)
-    DX_TILE_STORE(float, greg, Gs)
+    DX_TILE_STORE(CT, greg, Gs)
     if (tid < 64) { lse_s[tid] = lse_r; delta_s[tid] = delta_r; }
     __syncthreads();
     if (qt0 + 1 < ntiles) {
       DX_TILE_LOAD(QT, qreg, base, a.ld, h * HD, qbase + 64, a.N)
-      DX_TILE_LOAD(float, greg, gbase, a.ldc, h * HD, qbase + 64, a.N)
+      DX_TILE_LOAD(CT, greg, gbase, a.ldc, h * HD, qbase + 64, a.N)
       const int qn = qbase + 64 + tid;
       lse_r = (tid < 64 && qn < a.N) ? a.lse[(size_t)bh * a.N + qn] : 0.f;
       delta_r = (tid < 64 && qn < a.N) ? a.delta[(size_t)bh * a.N + qn] : 0.f;
@@ -892,10 +892,10 @@ int dx_attention_fwd(const void* qkvv, int ld, const int* lens, void* ctxv, int 
 }
 
 // dqkv (all three thirds, every row) from dctx; `delta` is scratch [B][H][N]
-int dx_attention_bwd(const void* qkvv, int ld, const void* ctxv, const float* dctx, int ldc, const float* lse, float* delta,
+int dx_attention_bwd(const void* qkvv, int ld, const void* ctxv, const void* dctxv, int ldc, const float* lse, float* delta,
                      const int* lens, void* dqkvv, int ldg, int B, int N, int H, int D, uint64_t seed, const uint64_t* seed_offset, float p_drop, int bf16,
                      int qkv_bf16, int dqkv_bf16, int ctx_bf16, void* stream) {
-  const float* qkv = (const float*)qkvv; float* dqkv = (float*)dqkvv; const float* ctx = (const float*)ctxv;
+  const float* qkv = (const float*)qkvv; float* dqkv = (float*)dqkvv; const float* ctx = (const float*)ctxv; const float* dctx = (const float*)dctxv;
   DX_REQUIRE(!ctx_bf16 || (bf16 && (ldc % 8) == 0), "dx_attention_bwd: a 16-bit context needs the 16-bit operand mode and ldc %% 8 == 0");
   if (int rc = check_common("dx_attention_bwd", qkv, ld, B, N, H, D)) return rc;
   DX_REQUIRE(!(qkv_bf16 || dqkv_bf16) || (bf16 && (ld % 8) == 0 && (ldg % 8) == 0), "dx_attention_bwd: bf16-stored qkv/dqkv need bf16 mode and ld %% 8 == 0");
@@ -912,9 +912,13 @@ int dx_attention_bwd(const void* qkvv, int ld, const void* ctxv, const float* dc
   if (bf16) {
     const dim3 grid(dx_cdiv(N, 64), H, B);
 #define DX_ATTN_BWD(QT_, OT_)                                                                          \
-    if (ctx_bf16) hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<QT_, OT_, dx_h16>), grid, dim3(256), 0, s, a);   \
-    else hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<QT_, OT_, float>), grid, dim3(256), 0, s, a);             \
-    hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<QT_, OT_>), grid, dim3(256), 0, s, a);
+    if (ctx_bf16) {                                                                                    \
+      hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<QT_, OT_, dx_h16>), grid, dim3(256), 0, s, a);       \
+      hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<QT_, OT_, dx_h16>), grid, dim3(256), 0, s, a);      \
+    } else {                                                                                           \
+      hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<QT_, OT_, float>), grid, dim3(256), 0, s, a);        \
+      hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<QT_, OT_, float>), grid, dim3(256), 0, s, a);       \
+    }
     if (qkv_bf16 && dqkv_bf16) { DX_ATTN_BWD(dx_h16, dx_h16) }
     else if (qkv_bf16) { DX_ATTN_BWD(dx_h16, float) }
     else if (dqkv_bf16) { DX_ATTN_BWD(float, dx_h16) }

@@ -225,7 +225,7 @@ class FFTBlockFn(torch.autograd.Function):
         dz1, da1, dln1_w, dln1_b = r1[:4]
         dproj = r1[5] if sh else (da1 if da1 is not None else dz1)
         dout_w, dout_b = ops.conv_wgrad(dproj, att, packs['out'], L, 0, arena=arena, w_sink=g('out_w'), b_sink=g('out_b'), prec=prec, defer=True)
-        datt = ops.conv_gemm(dproj, packs['out'], None, transpose=True, lens=L, halo=0, prec=prec)
+        datt = ops.conv_gemm(dproj, packs['out'], None, transpose=True, lens=L, halo=0, prec=prec, out_dtype=att.dtype)   # stored like the context
         dqkv = ops.attention_bwd(qkv, att, datt, lse, L, ctx.heads, s_attn, p_attn, out_dtype=qkv.dtype, prec=prec, seed_offset=so)
         din_w, din_b = ops.conv_wgrad(dqkv, x, packs['in'], L, 0, arena=arena, w_sink=g('in_w'), b_sink=g('in_b'), prec=prec, defer=True)
         dx = ops.conv_gemm(dqkv, packs['in'], None, transpose=True, out=dz1, accumulate=True, lens=L, halo=0, prec=prec)  # + residual branch

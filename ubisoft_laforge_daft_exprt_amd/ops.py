@@ -446,6 +446,8 @@ def attention_fwd(qkv, lens, heads, seed, p_drop, prec=None, seed_offset=None, c
 def attention_bwd(qkv, ctx, dctx, lse, lens, heads, seed, p_drop, out_dtype=torch.float32, prec=None, seed_offset=None):
     B, N, D3 = qkv.shape
     D = D3 // 3
+    if dctx.dtype != ctx.dtype:
+        raise TypeError(f'ctx ({ctx.dtype}) and dctx ({dctx.dtype}) must be stored alike')
     dqkv = torch.empty(B, N, D3, dtype=out_dtype, device=qkv.device)
     delta = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device)
     prec = prec or DEFAULT.precision
