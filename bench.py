@@ -83,7 +83,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--precision', default='bf16', choices=['f32', 'bf16'])
+    ap.add_argument('--precision', default='bf16', choices=['f32', 'bf16', 'fp16'])
     ap.add_argument('--config', default='C2', choices=['C1', 'C2', 'C5'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true')
@@ -235,15 +235,16 @@ def main():
             'metric': 'mel frames/sec (fwd+bwd)', 'value': round(total_frames * args.steps / elapsed, 1), 'unit': 'valid mel frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16' if args.precision == 'bf16' else 'f32', 'data': 'synthetic',
+            'dtype': {'bf16': 'bf16', 'fp16': 'f16', 'f32': 'f32'}[args.precision], 'data': 'synthetic',
             'config': {'workload': f'{args.config}: LJ-shaped training step, {cfg["batch_size"]} utterances/GPU, '
                                    f'L_max={int(batch[5].max())}, T_max={int(batch[9].max())}, {frames} valid frames/GPU/step; '
                                    'forward + loss (mel L1/L2, adversarial CE, post-mult, energy + pitch consistency) + backward'
                                    + (' + bucketed RCCL gradient all-reduce overlapped with backward' if world > 1 else '')
                                    + ' + fused Adam step (global-norm clip, LR schedule) + one-launch weight re-pack'
                                    + (', dropout OFF (diagnostic)' if args.no_dropout else ', dropout on'),
-                       'operands': 'bf16 MFMA operands for Conv1d/Linear GEMMs and attention, fp32 accumulate, 1024-wide hidden tensors and qkv stored bf16'
-                                   if args.precision == 'bf16' else 'exact f32 MFMA everywhere',
+                       'operands': (f'{args.precision} MFMA operands for Conv1d/Linear GEMMs and attention, fp32 accumulate; 1024-wide hidden tensors, qkv, '
+                                    f'attention context and their gradients stored {args.precision}' + (', static loss scale 4096' if args.precision == 'fp16' else ''))
+                                   if args.precision != 'f32' else 'exact f32 MFMA everywhere',
                        'parallelism': f'dp{world}', 'launch': 'eager (one Python call per kernel)' if args.no_graph else 'two captured HIP graphs per step + eager optimiser'},
         }
         result['rccl_ranks'] = dist.get_world_size() if world > 1 else 1
