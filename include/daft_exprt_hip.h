@@ -128,6 +128,13 @@ int dx_ln_fwd(void* a, const void* res, const float* w, const float* bias, const
               const int* lens, int halo, void* y, float* mean, float* rstd, int B, int N, int C,
               uint64_t seed_pre, float p_pre, uint64_t seed_post, float p_post, const uint64_t* seed_offset, int io_bf16, void* y_bf16_copy,
               void* stream);
+/* FiLM parameters of all FFT blocks in one launch: StyleAdapter.forward, model.py:779-800 (scalar post-multiplier affine, gamma | beta
+ * concatenation, per-block split).  gammas / betas: (B, nb*C) predictor outputs; pm: (2, nb) post-multipliers or null (then gamma + 1, beta);
+ * film: (nb, B, 2C), block i = the (B, 2C) tensor the LayerNorm kernels of FFT block i read.  The backward takes a HOST array of nb device
+ * pointers to the per-block gradients (null entries = no gradient), writes dgammas / dbetas and ACCUMULATES dpm (2, nb). */
+int dx_film_affine_fwd(const float* gammas, const float* betas, const float* pm, float* film, int B, int nb, int C, void* stream);
+int dx_film_affine_bwd(const void* dfilm_ptrs, const float* gammas, const float* betas, const float* pm, float* dgammas, float* dbetas, float* dpm,
+                       int B, int nb, int C, void* stream);
 /* Out-projection + dropout + residual + LayerNorm (+ FiLM + mask) of an FFT block in ONE launch (16-bit operand modes):
  *   z = dropout(X W^T + proj_bias) + res;  y = mask(FiLM(LayerNorm(z)))      attn.out_proj (model.py:165-186) + model.py:188-191
  * X: 16-bit [B*N][ldx], 128 columns (the attention context); Wpack: the forward pack (dx_pack_weights) of the (128, 128) weight.

@@ -373,6 +373,35 @@ def _attention_dropout_mask_consistency(ops, tol_f, tol_b):
     assert rel_err(dqkv, qkv_r.grad) < tol_b
 
 
+@pytest.mark.parametrize('with_pm', [True, False])
+def test_film_affine_forward_backward_vs_torch(ops, with_pm):
+    """FilmAffineFn (StyleAdapter tail, model.py:779-800) against the element-wise torch formulation, incl. blocks that receive no gradient."""
+    from ubisoft_laforge_daft_exprt_amd import functional as Fx
+    B, nb, C = 5, 8, 128
+    gam = randn(B, nb * C, seed=1).requires_grad_(True)
+    bet = randn(B, nb * C, seed=2).requires_grad_(True)
+    pm = randn(2, nb, seed=3).requires_grad_(True) if with_pm else None
+    *blocks, whole = Fx.FilmAffineFn.apply(gam, bet, pm, nb, None)
+    g = gam.view(B, nb, C)
+    b = bet.view(B, nb, C)
+    ref = torch.cat((pm[0][None, :, None] * g + 1, pm[1][None, :, None] * b), dim=2) if with_pm else torch.cat((g + 1, b), dim=2)
+    for i in range(nb):
+        assert blocks[i].is_contiguous() and rel_err(blocks[i], ref[:, i]) < 1e-6
+    assert rel_err(whole.transpose(0, 1), ref) < 1e-6
+    w = [randn(B, 2 * C, seed=10 + i) for i in range(nb)]
+    used = [0, 1, 3, 4, 5, 7]                                  # blocks 2 and 6 get no gradient
+    loss = sum((blocks[i] * w[i]).sum() for i in used)
+    loss.backward()
+    got = (gam.grad.clone(), bet.grad.clone(), None if pm is None else pm.grad.clone())
+    gam.grad = bet.grad = None
+    if pm is not None:
+        pm.grad = None
+    sum((ref[:, i] * w[i]).sum() for i in used).backward()
+    assert rel_err(got[0], gam.grad) < 1e-6 and rel_err(got[1], bet.grad) < 1e-6
+    if with_pm:
+        assert rel_err(got[2], pm.grad) < 1e-5
+
+
 @pytest.mark.parametrize('precision', ['bf16', 'fp16'])
 @pytest.mark.parametrize('p_drop', [0.0, 0.2])
 def test_ff_pair_layernorm_epilogue_equals_two_launches(ops, precision, p_drop):

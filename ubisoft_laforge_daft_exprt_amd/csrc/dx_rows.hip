@@ -666,6 +666,53 @@ __global__ __launch_bounds__(256) void channel_affine_kernel(const float* __rest
   }
 }
 
+// FiLM parameters of all FFT blocks from the two predictor outputs (StyleAdapter.forward, model.py:779-800):
+//   film[blk][b][0:C] = pm[0][blk] * gammas[b][blk*C + c] + 1,   film[blk][b][C:2C] = pm[1][blk] * betas[b][blk*C + c]      (pm = null: 1)
+// written block-major, (B, 2C) contiguous per block: what the LayerNorm kernels read.  One launch instead of mul, add, mul, cat, transpose.
+__global__ __launch_bounds__(256) void film_affine_fwd_kernel(const float* __restrict__ gammas, const float* __restrict__ betas, const float* __restrict__ pm,
+                                                              float* __restrict__ film, int B, int nb, int C) {
+  const long total = (long)nb * B * 2 * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c2 = (int)(i % (2 * C));
+    const int b = (int)((i / (2 * C)) % B);
+    const int blk = (int)(i / ((long)2 * C * B));
+    const bool beta = c2 >= C;
+    const int c = beta ? c2 - C : c2;
+    const float m = pm ? pm[(beta ? nb : 0) + blk] : 1.f;
+    const float v = (beta ? betas : gammas)[(size_t)b * nb * C + blk * C + c];
+    film[i] = beta ? m * v : m * v + 1.f;
+  }
+}
+
+// Backward: dgammas = pm[0][blk] * dfilm[blk][:, 0:C], dbetas likewise, dpm[0][blk] += sum dfilm_gamma * gammas, dpm[1][blk] += sum dfilm_beta * betas.
+// One block of 256 threads per (FFT block, half): the 2 nb scalar sums fold in LDS, one atomic each.  A null dfilm pointer = zero gradient.
+struct FilmBwdArgs {
+  const float* dfilm[16];        // per FFT block: (B, 2C) contiguous, or null
+  const float* gammas; const float* betas; const float* pm;
+  float* dgammas; float* dbetas; float* dpm;
+  int B, nb, C;
+};
+__global__ __launch_bounds__(256) void film_affine_bwd_kernel(const FilmBwdArgs a) {
+  const int blk = blockIdx.x, beta = blockIdx.y;
+  const float* df = a.dfilm[blk];
+  const float* src = beta ? a.betas : a.gammas;
+  float* dst = beta ? a.dbetas : a.dgammas;
+  const float m = a.pm ? a.pm[(beta ? a.nb : 0) + blk] : 1.f;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < a.B * a.C; i += 256) {
+    const int b = i / a.C, c = i - b * a.C;
+    const size_t o = (size_t)b * a.nb * a.C + blk * a.C + c;
+    const float d = df ? df[(size_t)b * 2 * a.C + (beta ? a.C : 0) + c] : 0.f;
+    dst[o] = m * d;
+    acc += d * src[o];
+  }
+  __shared__ float part[4];
+  acc = dx_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0 && a.dpm) atomicAdd(&a.dpm[(beta ? a.nb : 0) + blk], (part[0] + part[1]) + (part[2] + part[3]));
+}
+
 // per-speaker z-normalisation that preserves exact zeros (silence / unvoiced): dynamic_stats.py:156-183
 // table[s] = {energy mean, energy std, pitch mean, pitch std}; valid[s] = 0 -> utterance left untouched
 __global__ __launch_bounds__(256) void condition_prosody_kernel(const float* __restrict__ in, float* __restrict__ out, const long* __restrict__ spk,
@@ -883,6 +930,28 @@ int dx_channel_affine(const float* x, const float* scale, const float* shift, fl
   const long total4 = rows * C / 4;
   hipLaunchKernelGGL(channel_affine_kernel, dim3((int)std::min<long>((total4 + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, out, rows, C);
   DX_LAUNCH_CHECK("dx_channel_affine");
+  return DX_OK;
+}
+
+// film (nb, B, 2C) block-major from gammas / betas (B, nb*C) and the scalar post-multipliers pm (2, nb) or null: model.py:779-800
+int dx_film_affine_fwd(const float* gammas, const float* betas, const float* pm, float* film, int B, int nb, int C, void* stream) {
+  DX_REQUIRE(gammas && betas && film && B > 0 && nb > 0 && C > 0, "dx_film_affine_fwd: bad arguments");
+  const long total = (long)nb * B * 2 * C;
+  hipLaunchKernelGGL(film_affine_fwd_kernel, dim3((int)std::min<long>((total + 255) / 256, 1024)), dim3(256), 0, (hipStream_t)stream, gammas, betas, pm, film, B, nb, C);
+  DX_LAUNCH_CHECK("dx_film_affine_fwd");
+  return DX_OK;
+}
+
+// dfilm_ptrs: HOST array of nb device pointers ((B, 2C) contiguous each; null = that block received no gradient).  dpm (2, nb) accumulates.
+int dx_film_affine_bwd(const void* dfilm_ptrs, const float* gammas, const float* betas, const float* pm, float* dgammas, float* dbetas, float* dpm,
+                       int B, int nb, int C, void* stream) {
+  DX_REQUIRE(dfilm_ptrs && gammas && betas && dgammas && dbetas && B > 0 && nb > 0 && nb <= 16 && C > 0, "dx_film_affine_bwd: bad arguments (at most 16 blocks)");
+  DX_REQUIRE((pm == nullptr) == (dpm == nullptr), "dx_film_affine_bwd: pm and dpm must come together");
+  FilmBwdArgs a{};
+  for (int i = 0; i < nb; ++i) a.dfilm[i] = reinterpret_cast<const float* const*>(dfilm_ptrs)[i];
+  a.gammas = gammas; a.betas = betas; a.pm = pm; a.dgammas = dgammas; a.dbetas = dbetas; a.dpm = dpm; a.B = B; a.nb = nb; a.C = C;
+  hipLaunchKernelGGL(film_affine_bwd_kernel, dim3(nb, 2), dim3(256), 0, (hipStream_t)stream, a);
+  DX_LAUNCH_CHECK("dx_film_affine_bwd");
   return DX_OK;
 }
 

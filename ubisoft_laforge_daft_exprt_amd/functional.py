@@ -308,6 +308,29 @@ class SplitFilmFn(torch.autograd.Function):
         return torch.stack([g if g is not None else torch.zeros_like(ref) for g in grads], dim=1)
 
 
+class FilmAffineFn(torch.autograd.Function):
+    """StyleAdapter's tail (model.py:779-800) for all FFT blocks at once: scalar post-multiplier affine on the predicted gammas / betas,
+    (gamma | beta) concatenation and the per-block split -- one launch forward, one backward (was ~5 + ~10 ATen launches incl. two
+    full reductions for the post-multiplier gradients).  Returns nb contiguous (B, 2C) tensors (views of one block-major buffer)."""
+
+    @staticmethod
+    def forward(ctx, gammas, betas, pm, nb, rt):
+        gammas, betas = gammas.contiguous(), betas.contiguous()
+        pmc = None if pm is None else pm.detach().contiguous()
+        film = ops.film_affine_fwd(gammas, betas, pmc, nb)
+        ctx.save_for_backward(gammas, betas, pmc)
+        ctx.nb, ctx.rt, ctx.has_pm = nb, rt, pm is not None
+        whole = film.detach()                      # (nb, B, 2C): for the (B, nb, 2C) tensors of the reference's outputs[1] (strided views, no copy)
+        ctx.mark_non_differentiable(whole)
+        return tuple(film[i] for i in range(nb)) + (whole,)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gammas, betas, pm = ctx.saved_tensors
+        dg, db, dpm = ops.film_affine_bwd(list(grads[:ctx.nb]), gammas, betas, pm, arena=None if ctx.rt is None else ctx.rt.arena)
+        return dg, db, dpm, None, None
+
+
 class MeanPoolFn(torch.autograd.Function):
     """sum over time / length (model.py:714)."""
 

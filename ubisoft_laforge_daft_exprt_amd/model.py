@@ -10,6 +10,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import torch
 from torch import nn
 
@@ -252,6 +254,14 @@ class StyleAdapter(nn.Module):
             # into per-block tensors are done ONCE for all blocks (same element-wise arithmetic, a third of the glue launches)
             ch = chans.pop()
             nb_all = sum(nb for nb, _ in self.module_params.values())
+            if gammas.is_cuda and os.environ.get('DX_FILM_FUSED', '1') != '0':      # one launch forward, one backward (functional.FilmAffineFn)
+                pm = self.post_multipliers if self.post_mult_weight != 0.0 else None
+                *blocks, whole = Fx.FilmAffineFn.apply(gammas, betas, pm, nb_all, getattr(self, '_dx_rt', None))
+                for name, (nb, _) in self.module_params.items():
+                    # the (B, nb, 2C) tensor of the reference's return value: a strided view of the block-major buffer
+                    out[name] = FilmSet(blocks[blk:blk + nb], whole[blk:blk + nb].transpose(0, 1))
+                    blk += nb
+                return out
             g = gammas.view(B, nb_all, ch)
             b = betas.view(B, nb_all, ch)
             if self.post_mult_weight != 0.0:

@@ -422,6 +422,28 @@ def flush_wgrads(rt) -> int:
     return launches
 
 
+def film_affine_fwd(gammas, betas, pm, nb):
+    """(B, nb*C) predictor outputs + (2, nb) post-multipliers (or None) -> (nb, B, 2C) block-major FiLM parameters."""
+    B, total = gammas.shape
+    C = total // nb
+    film = torch.empty(nb, B, 2 * C, dtype=torch.float32, device=gammas.device)
+    lib().dx_film_affine_fwd(_p(gammas), _p(betas), _p(pm), _p(film), B, nb, C, _stream())
+    return film
+
+
+def film_affine_bwd(dfilms, gammas, betas, pm, arena=None):
+    """``dfilms``: list of nb (B, 2C) gradients or None.  Returns (dgammas, dbetas, dpm or None)."""
+    B, total = gammas.shape
+    nb = len(dfilms)
+    C = total // nb
+    dfilms = [None if g is None else g.contiguous() for g in dfilms]
+    ptrs = (ctypes.c_void_p * nb)(*[None if g is None else g.data_ptr() for g in dfilms])
+    dg, db = torch.empty_like(gammas), torch.empty_like(betas)
+    dpm = _zeros(arena, 2, nb, device=gammas.device) if pm is not None else None
+    lib().dx_film_affine_bwd(ctypes.addressof(ptrs), _p(gammas), _p(betas), _p(pm), _p(dg), _p(db), _p(dpm), B, nb, C, _stream())
+    return dg, db, dpm
+
+
 def colsum(x, C=None):
     C = x.shape[-1] if C is None else C
     rows = x.numel() // x.shape[-1]
