@@ -105,6 +105,14 @@ int dx_ff_pair_ln(const void* X, int ldx, const void* Wa, const void* Wb, const 
                   int B, int N, int F, const int* lens, int skip_halo, const int* rows_exist,
                   const float* res, const float* ln_w, const float* ln_b, const float* film, int ld_film, float* Yln, float* mean, float* rstd,
                   uint64_t seed_pre, float p_pre, const uint64_t* seed_offset, void* stream);
+/* dx_ff_pair (input-gradient pair, accumulate = 1) with the BACKWARD of the block's first LayerNorm folded into its epilogue: Y holds the
+ * residual-branch gradient on entry and dz1 = LayerNorm-backward(Y + pair result) on return; DG (16-bit [B][N][128]) = dropout(dz1), the
+ * operand of the out-projection's backward GEMMs; dw / db (caller-initialised [128]) accumulate the affine gradients.  z / mean / rstd /
+ * ln_w / ln_b / seed_pre / p_pre: the arguments of dx_ln_bwd with C = 128, no FiLM, halo 0 (model.py:188-191 backward). */
+int dx_ff_pair_lnbwd(const void* X, int ldx, const void* Wa, const void* Wb, const void* aux, int ld_aux, void* H, int ldh, float* Y,
+                     int B, int N, int F, const int* lens, int skip_halo,
+                     const float* z, const float* mean, const float* rstd, const float* ln_w, const float* ln_b, void* DG, float* dw, float* db,
+                     uint64_t seed_pre, float p_pre, const uint64_t* seed_offset, void* stream);
 /* out[c] += sum_rows X[row][c]   (bias gradients) */
 int dx_colsum(const void* X, int ldx, float* out, long rows, int C, int x_bf16, void* stream);
 

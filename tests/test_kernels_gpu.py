@@ -373,6 +373,42 @@ def _attention_dropout_mask_consistency(ops, tol_f, tol_b):
     assert rel_err(dqkv, qkv_r.grad) < tol_b
 
 
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+@pytest.mark.parametrize('p_drop', [0.0, 0.2])
+def test_ff_pair_backward_layernorm_epilogue_equals_two_launches(ops, precision, p_drop):
+    """dx_ff_pair_lnbwd == dx_ff_pair(backward, accumulate) followed by dx_ln_bwd (same seeds): dz1, its dropped-out 16-bit copy, dh and the
+    affine gradients; lengths on a tile edge, on the halo row and inside a tile."""
+    ops.set_precision(precision)
+    try:
+        h16 = ops.hidden_dtype()
+        B, N, Fc = 5, 300, 1024
+        lens = lens_tensor([300, 252, 126, 127, 40])
+        valid = (torch.arange(N, device=DEV)[None, :] < lens[:, None])
+        vf = valid[:, :, None].float()
+        w1 = randn(Fc, 128, 3, seed=2, scale=1 / math.sqrt(384))
+        w2 = randn(128, Fc, 3, seed=4, scale=1 / math.sqrt(3 * Fc))
+        p1, p2 = ops.PackedWeight(w1), ops.PackedWeight(w2)
+        x = (randn(B, N, 128, seed=1) * vf).to(h16)
+        h = ops.conv_gemm(x, p1, randn(Fc, seed=3, scale=0.1), relu=True, lens=lens, halo=1, out_dtype=h16)     # the stored forward activation (mask)
+        dff = (randn(B, N, 128, seed=5) * vf).to(h16)
+        resid = randn(B, N, 128, seed=6) * vf                                # the residual-branch gradient already in the output buffer
+        z = randn(B, N, 128, seed=7)
+        mean, rstd = z.mean(dim=2), 1.0 / torch.sqrt(z.var(dim=2, unbiased=False) + 1e-5)
+        lw, lb = 1 + 0.1 * randn(128, seed=8), randn(128, seed=9, scale=0.1)
+        out0 = resid.clone()
+        dy1, dh0 = ops.ff_pair(dff, p1, p2, None, None, lens, backward=True, aux=h, out=out0, accumulate=True)
+        r = ops.ln_bwd(dy1, z, mean, rstd, lw, lb, None, lens, want_da=p_drop > 0, seed_pre=55, p_pre=p_drop, shadow=True)
+        dz0, dw0, db0, dg0 = r[0], r[2], r[3], r[5]
+        out1 = resid.clone()
+        dz1, dh1, dg1, dw1, db1 = ops.ff_pair_lnbwd(dff, p1, p2, lens, h, out1, z, mean, rstd, lw, lb, seed_pre=55, p_pre=p_drop)
+        assert dz1.data_ptr() == out1.data_ptr() and torch.equal(dh0, dh1)
+        assert rel_err(dz1, dz0) < 1e-5 and float(dz1[~valid].abs().max()) == 0.0
+        assert rel_err(dg1.float(), dg0.float()) < 1e-2 and float(dg1[~valid].float().abs().max()) == 0.0
+        assert rel_err(dw1, dw0) < 1e-4 and rel_err(db1, db0) < 1e-4
+    finally:
+        ops.set_precision('f32')
+
+
 @pytest.mark.parametrize('with_pm', [True, False])
 def test_film_affine_forward_backward_vs_torch(ops, with_pm):
     """FilmAffineFn (StyleAdapter tail, model.py:779-800) against the element-wise torch formulation, incl. blocks that receive no gradient."""

@@ -51,6 +51,11 @@ struct FFPairArgs {
   const float* ln_res; const float* ln_w; const float* ln_b; const float* film; int ld_film;
   float* ln_y; float* ln_mean; float* ln_rstd;
   unsigned long long seed_pre; unsigned thresh_pre; float inv_keep_pre; const unsigned long long* seed_offset;
+  // optional LayerNorm-BACKWARD epilogue of the input-gradient pair (lnb_w != null): the pair's result + the residual gradient already in Y
+  // is d(loss)/d(y1) of the block's FIRST LayerNorm; the epilogue turns the tile into dz1 (written to Y), its dropped-out 16-bit copy for the
+  // GEMMs (lnb_dg) and the affine gradients (lnb_dw / lnb_db, atomics) -- dx_ln_bwd with C = 128, no FiLM, halo 0, done while the tile is in LDS
+  const float* lnb_z; const float* lnb_mean; const float* lnb_rstd; const float* lnb_w; const float* lnb_b;
+  dx_h16* lnb_dg; float* lnb_dw; float* lnb_db;
   unsigned long long* stamps;        // diagnostic builds (-DDX_FFPAIR_STAMPS, tools/ffpair_stamps.py) only: [workgroup][role][16] s_memtime values
 };
 
@@ -178,6 +183,11 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
       const int row = u / hu, q = u - row * hu;
       *reinterpret_cast<f32x4*>(a.H + ((size_t)b * a.N + n0 + row) * a.ldh + q * 8) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    if (a.lnb_w)
+      for (int u = tid; u < rows * 16; u += 512) {        // 16-bit gradient copy: 16 x 16 bytes per row
+        const int row = u >> 4, q = u & 15;
+        *reinterpret_cast<f32x4*>(a.lnb_dg + ((size_t)b * a.N + n0 + row) * 128 + q * 8) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     if (!a.accumulate)
       for (int u = tid; u < rows * 32; u += 512) {
         const int row = u >> 5, q = u & 31;
@@ -457,6 +467,66 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
       if (!valid) y = f32x4{0.f, 0.f, 0.f, 0.f};
       if (inb) *reinterpret_cast<f32x4*>(a.ln_y + grow * 128 + s * 4) = y;
     }
+  } else if (a.lnb_w) {
+    // LayerNorm-backward epilogue (the block's first LayerNorm): same arithmetic as ln_bwd_kernel<128, float, false>
+    const int s = tid & 31;
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(a.lnb_w + s * 4), bv = *reinterpret_cast<const f32x4*>(a.lnb_b + s * 4);
+    (void)bv;
+    const int len_b = a.lens ? a.lens[b] : a.N;
+    const unsigned long long seed = a.seed_pre + (a.seed_offset ? *a.seed_offset : 0ull);
+    f32x4 oldv[8], zv[8];
+    float muv[8], rsv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                       // all global reads of the eight passes first
+      const int row = (tid >> 5) + k * 16, n = n0 + row;
+      const bool valid = row < len_cols && n < len_b;
+      const size_t grow = (size_t)b * a.N + n;
+      oldv[k] = valid ? *reinterpret_cast<const f32x4*>(a.Y + grow * a.ldy + s * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      zv[k] = valid ? *reinterpret_cast<const f32x4*>(a.lnb_z + grow * 128 + s * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      muv[k] = valid ? a.lnb_mean[grow] : 0.f;
+      rsv[k] = valid ? a.lnb_rstd[grow] : 0.f;
+    }
+    f32x4 gw = f32x4{0.f, 0.f, 0.f, 0.f}, gb = gw;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int row = (tid >> 5) + k * 16, n = n0 + row;
+      const bool inb = row < len_cols, valid = inb && n < len_b;
+      const size_t grow = (size_t)b * a.N + n;
+      f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (valid) d = *reinterpret_cast<const f32x4*>(stage + row * 512 + ((s ^ (row & 15)) << 4)) + oldv[k];
+      const f32x4 xh = (zv[k] - muv[k]) * rsv[k];
+      gw += d * xh; gb += d;
+      const f32x4 g = d * wv;
+      float s1 = (g[0] + g[1]) + (g[2] + g[3]);
+      const f32x4 gx = g * xh;
+      float s2 = (gx[0] + gx[1]) + (gx[2] + gx[3]);
+#pragma unroll
+      for (int off = 1; off < 32; off <<= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+      s1 *= (1.0f / 128); s2 *= (1.0f / 128);
+      f32x4 dz = (g - s1 - xh * s2) * rsv[k];
+      if (!inb) continue;
+      *reinterpret_cast<f32x4*>(a.Y + grow * a.ldy + s * 4) = dz;                  // dz1: the residual-branch gradient (the dz2 row it replaces is dead)
+      if (a.thresh_pre) {
+        float f[4];
+        dx_dropout_scale4(seed, (unsigned long long)grow * 128 + s * 4, a.thresh_pre, a.inv_keep_pre, f);
+        dz[0] *= f[0]; dz[1] *= f[1]; dz[2] *= f[2]; dz[3] *= f[3];
+      }
+      bf16x4 h4;
+      h4[0] = (dx_h16)dz[0]; h4[1] = (dx_h16)dz[1]; h4[2] = (dx_h16)dz[2]; h4[3] = (dx_h16)dz[3];
+      *reinterpret_cast<bf16x4*>(a.lnb_dg + grow * 128 + s * 4) = h4;
+    }
+    // affine gradients: 16 row groups x 128 channels fold through LDS (behind the staging tile), one atomic per channel per workgroup
+    float* const red = reinterpret_cast<float*>(smem + 128 * 512);
+    *reinterpret_cast<f32x4*>(red + (tid >> 5) * 128 + s * 4) = gw;
+    *reinterpret_cast<f32x4*>(red + 2048 + (tid >> 5) * 128 + s * 4) = gb;
+    __syncthreads();
+    if (tid < 256) {
+      const float* src = red + (tid >> 7) * 2048 + (tid & 127);
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t += src[q * 128];
+      if (t != 0.f) atomicAdd((tid >> 7) ? &a.lnb_db[tid & 127] : &a.lnb_dw[tid & 127], t);
+    }
   } else {
     f32x4 old[8];
     if (a.accumulate) {
@@ -501,13 +571,19 @@ static int ff_pair_launch(const void* X, int ldx, const void* Wa, const void* Wb
                           int B, int N, int F, int relu_mid, int accumulate, const int* lens, int skip_halo, const int* rows_exist,
                           const float* ln_res, const float* ln_w, const float* ln_b, const float* film, int ld_film,
                           float* ln_y, float* ln_mean, float* ln_rstd, unsigned long long seed_pre, float p_pre, const unsigned long long* seed_offset,
-                          void* stream) {
+                          const float* lnb_z, const float* lnb_mean, const float* lnb_rstd, const float* lnb_w, const float* lnb_b,
+                          void* lnb_dg, float* lnb_dw, float* lnb_db, void* stream) {
   DX_REQUIRE(X && Wa && Wb && H && Y, "dx_ff_pair: null pointer");
   if (ln_w) {
     DX_REQUIRE(relu_mid && !accumulate && lens && skip_halo >= 0 && ldy == 128, "dx_ff_pair_ln: forward pair, no accumulate, lens, dense Z");
     DX_REQUIRE(ln_res && ln_b && ln_y && ln_mean && ln_rstd, "dx_ff_pair_ln: null pointer");
     DX_REQUIRE(!film || ld_film >= 256, "dx_ff_pair_ln: ld_film too small");
     DX_REQUIRE(p_pre >= 0.f && p_pre < 1.f, "dx_ff_pair_ln: dropout p out of range");
+  }
+  if (lnb_w) {
+    DX_REQUIRE(aux && accumulate && lens && skip_halo >= 0 && ldy == 128 && !ln_w, "dx_ff_pair_lnbwd: input-gradient pair accumulating onto a dense Y, lens required");
+    DX_REQUIRE(lnb_z && lnb_mean && lnb_rstd && lnb_b && lnb_dg && lnb_dw && lnb_db, "dx_ff_pair_lnbwd: null pointer");
+    DX_REQUIRE(p_pre >= 0.f && p_pre < 1.f && ((uintptr_t)lnb_dg % 16) == 0, "dx_ff_pair_lnbwd: bad dropout p or alignment");
   }
   DX_REQUIRE(B > 0 && N > 0 && F >= 128 && (F % 128) == 0, "dx_ff_pair: bad dims B=%d N=%d F=%d (F must be a multiple of 128)", B, N, F);
   DX_REQUIRE(ldx >= 128 && (ldx % 8) == 0 && ldh >= F && (ldh % 8) == 0 && ldy >= 128 && (ldy % 4) == 0, "dx_ff_pair: bad leading dimensions");
@@ -518,7 +594,8 @@ static int ff_pair_launch(const void* X, int ldx, const void* Wa, const void* Wb
              ((uintptr_t)Y % 16) == 0 && ((uintptr_t)aux % 8) == 0, "dx_ff_pair: pointers must be 16-byte aligned");
   FFPairArgs a{(const dx_h16*)X, ldx, (const dx_h16*)Wa, (const dx_h16*)Wb, bias_a, bias_b, (const dx_h16*)aux, ld_aux,
                (dx_h16*)H, ldh, Y, ldy, B, N, F, accumulate, lens, skip_halo, rows_exist,
-               ln_res, ln_w, ln_b, film, ld_film, ln_y, ln_mean, ln_rstd, seed_pre, (unsigned)lrintf(p_pre * 65536.f), 1.f / (1.f - p_pre), seed_offset, nullptr};
+               ln_res, ln_w, ln_b, film, ld_film, ln_y, ln_mean, ln_rstd, seed_pre, (unsigned)lrintf(p_pre * 65536.f), 1.f / (1.f - p_pre), seed_offset,
+               lnb_z, lnb_mean, lnb_rstd, lnb_w, lnb_b, (dx_h16*)lnb_dg, lnb_dw, lnb_db, nullptr};
 #ifdef DX_FFPAIR_STAMPS
   a.stamps = g_ffpair_stamps;
 #endif
@@ -542,7 +619,8 @@ int dx_ff_pair(const void* X, int ldx, const void* Wa, const void* Wb, const flo
                const void* aux, int ld_aux, void* H, int ldh, float* Y, int ldy,
                int B, int N, int F, int relu_mid, int accumulate, const int* lens, int skip_halo, const int* rows_exist, void* stream) {
   return ff_pair_launch(X, ldx, Wa, Wb, bias_a, bias_b, aux, ld_aux, H, ldh, Y, ldy, B, N, F, relu_mid, accumulate, lens, skip_halo, rows_exist,
-                        nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0ull, 0.f, nullptr, stream);
+                        nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0ull, 0.f, nullptr,
+                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 // The forward pair with the block's second LayerNorm folded into its epilogue:
@@ -554,7 +632,22 @@ int dx_ff_pair_ln(const void* X, int ldx, const void* Wa, const void* Wb, const 
                   uint64_t seed_pre, float p_pre, const uint64_t* seed_offset, void* stream) {
   DX_REQUIRE(ln_w != nullptr, "dx_ff_pair_ln: null pointer");
   return ff_pair_launch(X, ldx, Wa, Wb, bias_a, bias_b, nullptr, 0, H, ldh, Z, 128, B, N, F, 1, 0, lens, skip_halo, rows_exist,
-                        res, ln_w, ln_b, film, ld_film, Yln, mean, rstd, (unsigned long long)seed_pre, p_pre, (const unsigned long long*)seed_offset, stream);
+                        res, ln_w, ln_b, film, ld_film, Yln, mean, rstd, (unsigned long long)seed_pre, p_pre, (const unsigned long long*)seed_offset,
+                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+// The input-gradient pair with the backward of the block's FIRST LayerNorm folded into its epilogue:
+//   dy1 = Y (the residual-branch gradient dz2, already there) + conv1^T(mask(conv2^T(X)))          as dx_ff_pair(accumulate = 1)
+//   Y <- dz1 = LayerNorm-backward(dy1; z, mean, rstd, w)   DG <- dropout(dz1) (16-bit)   dw / db += the affine gradients
+// i.e. dx_ln_bwd(C = 128, no FiLM, halo 0, 16-bit shadow) on the output tile while it is in LDS.
+int dx_ff_pair_lnbwd(const void* X, int ldx, const void* Wa, const void* Wb, const void* aux, int ld_aux, void* H, int ldh, float* Y,
+                     int B, int N, int F, const int* lens, int skip_halo,
+                     const float* z, const float* mean, const float* rstd, const float* ln_w, const float* ln_b, void* DG, float* dw, float* db,
+                     uint64_t seed_pre, float p_pre, const uint64_t* seed_offset, void* stream) {
+  DX_REQUIRE(ln_w != nullptr, "dx_ff_pair_lnbwd: null pointer");
+  return ff_pair_launch(X, ldx, Wa, Wb, nullptr, nullptr, aux, ld_aux, H, ldh, Y, 128, B, N, F, 0, 1, lens, skip_halo, nullptr,
+                        nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, (unsigned long long)seed_pre, p_pre, (const unsigned long long*)seed_offset,
+                        z, mean, rstd, ln_w, ln_b, DG, dw, db, stream);
 }
 
 }  // extern "C"

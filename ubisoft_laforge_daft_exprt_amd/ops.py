@@ -328,6 +328,27 @@ def ff_pair_ln(x, pack1: PackedWeight, pack2: PackedWeight, bias1, bias2, lens, 
     return z, h, y, mean, rstd
 
 
+_FF_LNBWD = os.environ.get('DX_FF_LNBWD', '1') != '0'
+
+
+def ff_pair_lnbwd(x, pack1: PackedWeight, pack2: PackedWeight, lens, aux, out, z, mean, rstd, ln_w, ln_b, *, seed_pre=0, p_pre=0.0, seed_offset=None,
+                  halo=1, prec=None, arena=None, w_sink=None, b_sink=None):
+    """The input-gradient pair with the backward of the block's first LayerNorm in its epilogue (dx_ff_pair_lnbwd).  ``out`` holds the
+    residual-branch gradient on entry and dz1 on return.  Returns (dz1 (= out), dh, dg_16bit, dw or None, db or None)."""
+    prec = pack1.rt.precision if prec is None else prec
+    B, N, D = x.shape
+    Fc = pack1.cout
+    i1, i2 = pack1.image(prec), pack2.image(prec)
+    dh = torch.empty(B, N, Fc, dtype=_H16[prec], device=x.device)
+    dg = torch.empty(B, N, 128, dtype=_H16[prec], device=x.device)
+    dw = w_sink if w_sink is not None else _zeros(arena, 128, device=x.device)
+    db = b_sink if b_sink is not None else _zeros(arena, 128, device=x.device)
+    _log(pack1, ('ffpair', B * N, N, 128, Fc, 3))
+    _fn('dx_ff_pair_lnbwd', prec)(_p(x), _rows(x), _p(i2.bwd), _p(i1.bwd), _p(aux), _rows(aux), _p(dh), _rows(dh), _p(out), B, N, Fc, _p(lens), int(halo),
+                                  _p(z), _p(mean), _p(rstd), _p(ln_w), _p(ln_b), _p(dg), _p(dw), _p(db), seed_pre, float(p_pre), _p(seed_offset), _stream())
+    return out, dh, dg, (None if w_sink is not None else dw), (None if b_sink is not None else db)
+
+
 class ZeroArena:
     """One zero-filled buffer handed out in 16-byte aligned slices: the many small accumulators (atomic targets) of one
     backward call cost a single memset launch instead of one each."""
