@@ -102,11 +102,19 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
+    # Rehearsal of the multi-rank path on a ONE-GPU box (DX_BENCH_REHEARSAL=1): every rank uses cuda:0 and the gradients travel over gloo.
+    # It exercises the trainer / graph / bucket-group code of N > 1 end to end; its numbers mean nothing (one GPU shared, host-staged all-reduce).
+    rehearsal = os.environ.get('DX_BENCH_REHEARSAL', '0') == '1'
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     import ubisoft_laforge_daft_exprt_amd as pkg
     from ubisoft_laforge_daft_exprt_amd import ops
