@@ -60,9 +60,17 @@ class GradientReducer:
             self.buckets.append(cur)
             self.bucket_group.append(cur_g)
         self.flat, self.bucket_of = [], {}
+        # ONE allocation for all buckets (each a 16-byte aligned slice): zeroing, the gradient norm and the fused Adam step are then one
+        # launch each over the whole range instead of one per bucket; the gaps between buckets stay zero
+        sizes = [sum(p.numel() for p in bucket) for bucket in self.buckets]
+        self.bucket_offset, total = [], 0
+        for n in sizes:
+            self.bucket_offset.append(total)
+            total += (n + 3) // 4 * 4
+        self.flat_all = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
         for bi, bucket in enumerate(self.buckets):
-            n = sum(p.numel() for p in bucket)
-            flat = torch.zeros(n, dtype=bucket[0].dtype, device=bucket[0].device)
+            n = sizes[bi]
+            flat = self.flat_all[self.bucket_offset[bi]:self.bucket_offset[bi] + n]
             off = 0
             for p in bucket:
                 p.grad = flat[off:off + p.numel()].view_as(p)
@@ -97,8 +105,7 @@ class GradientReducer:
 
     def zero_grad(self):
         """Keeps the grad views alive (set_to_none would detach them from the buckets)."""
-        for flat in self.flat:
-            flat.zero_()
+        self.flat_all.zero_()
         self.launched.clear()
         self.pending = [len(b) for b in self.buckets]
 

@@ -34,8 +34,13 @@ class FusedAdam:
         self.runtime = getattr(reducer.module, 'runtime', None) or ops.DEFAULT
         self.pflat, self.m, self.v = [], [], []
         self._slot = {}                                # parameter -> (bucket index, offset)
+        # parameters and both moments mirror the reducer's single gradient allocation (same offsets): one launch steps everything
+        self.p_all = torch.zeros_like(reducer.flat_all)
+        self.m_all = torch.zeros_like(reducer.flat_all)
+        self.v_all = torch.zeros_like(reducer.flat_all)
         for bi, (bucket, gflat) in enumerate(zip(reducer.buckets, reducer.flat)):
-            pflat = torch.empty_like(gflat)
+            o0 = reducer.bucket_offset[bi]
+            pflat = self.p_all[o0:o0 + gflat.numel()]
             off = 0
             for p in bucket:                       # re-home every parameter inside the flat bucket (same offsets as its gradient)
                 n = p.numel()
@@ -44,8 +49,8 @@ class FusedAdam:
                 self._slot[p] = (bi, off)
                 off += n
             self.pflat.append(pflat)
-            self.m.append(torch.zeros_like(gflat))
-            self.v.append(torch.zeros_like(gflat))
+            self.m.append(self.m_all[o0:o0 + gflat.numel()])
+            self.v.append(self.v_all[o0:o0 + gflat.numel()])
         self.normsq = torch.zeros(1, dtype=torch.float32, device=reducer.flat[0].device)
         # torch.optim order: the trainable parameters in registration order (the reducer holds them reversed, in buckets)
         self.params = [p for p in reducer.module.parameters() if p.requires_grad]
@@ -63,11 +68,10 @@ class FusedAdam:
             self.lr = lr
         self.step_count += 1
         self.normsq.zero_()
-        for g in self.reducer.flat:
-            lib().dx_sumsq(_p(g), g.numel(), _p(self.normsq), _stream())
-        for p, g, m, v in zip(self.pflat, self.reducer.flat, self.m, self.v):
-            lib().dx_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), float(self.lr), self.betas[0], self.betas[1], float(self.eps),
-                               float(self.weight_decay), self.step_count, _p(self.normsq), float(self.max_norm), float(grad_scale), _stream())
+        g = self.reducer.flat_all                   # all buckets (the alignment gaps hold zeros: they add nothing and stay zero)
+        lib().dx_sumsq(_p(g), g.numel(), _p(self.normsq), _stream())
+        lib().dx_adam_step(_p(self.p_all), _p(g), _p(self.m_all), _p(self.v_all), g.numel(), float(self.lr), self.betas[0], self.betas[1], float(self.eps),
+                           float(self.weight_decay), self.step_count, _p(self.normsq), float(self.max_norm), float(grad_scale), _stream())
         self.runtime.invalidate_packs()             # parameters were written behind autograd's back: force a re-pack ...
         ops.repack_all(self.runtime)                # ... which is one launch for the whole model
         return self.normsq.sqrt() * grad_scale if grad_scale != 1.0 else self.normsq.sqrt()
