@@ -510,45 +510,54 @@ __global__ __launch_bounds__(256) void scalar_conv_wgrad_kernel(const float* __r
                                                                 float* __restrict__ dw0, float* __restrict__ db0,
                                                                 float* __restrict__ dw1, float* __restrict__ db1,
                                                                 int B, int N, int rows_per_block) {
+  // thread = 4 channels (32 threads per row, 16-byte loads of dout) x one of 8 row groups; the scalar streams of the block's rows
+  // (+ one halo row each side) sit in LDS.  (One channel per thread and one 4-byte load per row ran at 2 % of the HBM rate: 54 us
+  // for 22 MB.)
   constexpr int D = 128;
-  const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
+  const int q = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int b = blockIdx.y;
   const int n_begin = blockIdx.x * rows_per_block;
   const int n_end = min(min(N, n_begin + rows_per_block), lens[b]);
-  float a0[3] = {0.f, 0.f, 0.f}, a1[3] = {0.f, 0.f, 0.f}, ab = 0.f;
-  const float* x0 = s0 + (size_t)b * N;
-  const float* x1 = s1 ? s1 + (size_t)b * N : nullptr;
+  __shared__ float xs[2][256 + 2];
+  __shared__ float rsc[256];
+  for (int i = threadIdx.x; i < rows_per_block + 2; i += 256) {
+    const int m = n_begin - 1 + i;
+    const bool in = m >= 0 && m < N;
+    xs[0][i] = in ? s0[(size_t)b * N + m] : 0.f;
+    xs[1][i] = (in && s1) ? s1[(size_t)b * N + m] : 0.f;
+  }
+  for (int i = threadIdx.x; i < rows_per_block; i += 256) rsc[i] = (rowscale && n_begin + i < N) ? rowscale[(size_t)b * N + n_begin + i] : 1.f;
+  __syncthreads();
+  f32x4 a0[3], a1[3], ab = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 3; ++t) { a0[t] = f32x4{0.f, 0.f, 0.f, 0.f}; a1[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll 4
-  for (int n = n_begin + half; n < n_end; n += 2) {
-    float g = dout[((size_t)b * N + n) * ldd + c];
-    if (rowscale) g *= rowscale[(size_t)b * N + n];
+  for (int n = n_begin + grp; n < n_end; n += 8) {
+    f32x4 g = *reinterpret_cast<const f32x4*>(dout + ((size_t)b * N + n) * ldd + q * 4);
+    const int i = n - n_begin;
+    g *= rsc[i];
     ab += g;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const int m = n + t - 1;
-      const bool in = m >= 0 && m < N;
-      a0[t] += g * (in ? x0[m] : 0.f);
-      if (x1) a1[t] += g * (in ? x1[m] : 0.f);
-    }
+    for (int t = 0; t < 3; ++t) { a0[t] += g * xs[0][i + t]; a1[t] += g * xs[1][i + t]; }
   }
-  // the two row-halves fold in LDS first: every atomic here lands on one of ~1 k addresses, and same-address atomics
-  // serialise (672 blocks x 256 threads x 8 of them took most of this kernel's 49 us)
-  __shared__ float fold[7][D];
-  if (half == 1) {
+  // the eight row groups fold in LDS first: every atomic lands on one of ~1 k addresses and same-address atomics serialise
+  __shared__ float fold[8][7][D];
 #pragma unroll
-    for (int t = 0; t < 3; ++t) { fold[t][c] = a0[t]; fold[3 + t][c] = a1[t]; }
-    fold[6][c] = ab;
+  for (int t = 0; t < 3; ++t) {
+    *reinterpret_cast<f32x4*>(&fold[grp][t][q * 4]) = a0[t];
+    *reinterpret_cast<f32x4*>(&fold[grp][3 + t][q * 4]) = a1[t];
   }
+  *reinterpret_cast<f32x4*>(&fold[grp][6][q * 4]) = ab;
   __syncthreads();
-  if (half == 0) {
+  for (int u = threadIdx.x; u < 7 * D; u += 256) {
+    const int k = u / D, c = u - k * D;
+    float v = 0.f;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const float v0 = a0[t] + fold[t][c];
-      if (v0 != 0.f) atomicAdd(&dw0[c * 3 + t], v0);
-      if (x1) { const float v1 = a1[t] + fold[3 + t][c]; if (v1 != 0.f) atomicAdd(&dw1[c * 3 + t], v1); }
-    }
-    const float vb = ab + fold[6][c];
-    if (vb != 0.f) { atomicAdd(&db0[c], vb); if (x1) atomicAdd(&db1[c], vb); }
+    for (int gq = 0; gq < 8; ++gq) v += fold[gq][k][c];
+    if (v == 0.f) continue;
+    if (k < 3) atomicAdd(&dw0[c * 3 + k], v);
+    else if (k < 6) { if (s1) atomicAdd(&dw1[c * 3 + (k - 3)], v); }
+    else { atomicAdd(&db0[c], v); if (s1) atomicAdd(&db1[c], v); }
   }
 }
 
@@ -875,7 +884,10 @@ int dx_scalar_conv_wgrad(const float* dout, int ldd, const float* rowscale, cons
   DX_REQUIRE(dout && s0 && lens && dw0 && db0, "dx_scalar_conv_wgrad: null pointer");
   DX_REQUIRE(D == 128 && ldd >= 0, "dx_scalar_conv_wgrad: hidden dim must be 128");  // ldd == 0: one row broadcast
   DX_REQUIRE(!s1 || (dw1 && db1), "dx_scalar_conv_wgrad: second stream needs its gradient buffers");
-  const int rpb = 64;       // with the row halves folded in LDS, short blocks win again (N/2, N/4, N/8, 64 rows: 66 / 40 / 31 / 30 us)
+  static const int rpb_env = getenv("DX_SCW_RPB") ? atoi(getenv("DX_SCW_RPB")) : 0;
+  // every block ends in 7 x 128 atomics on the same ~900 addresses, and same-address atomics cost ~70 ns each when all blocks finish together:
+  // the launch time is proportional to the number of blocks (32 / 64 / 128 / 256 rows per block: 95 / 51 / 30 / 20 us on the frame axis)
+  const int rpb = rpb_env > 0 ? std::min(rpb_env, 256) : 256;
   hipLaunchKernelGGL(scalar_conv_wgrad_kernel, dim3(dx_cdiv(N, rpb), B), dim3(256), 0, (hipStream_t)stream,
                      dout, ldd, rowscale, s0, s1, lens, dw0, db0, dw1, db1, B, N, rpb);
   DX_LAUNCH_CHECK("dx_scalar_conv_wgrad");
