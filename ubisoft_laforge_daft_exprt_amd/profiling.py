@@ -52,6 +52,8 @@ def price(name, a, geom: Geometry):
     """-> (kernel label, bound, algorithmic FLOPs, algorithmic HBM bytes); bytes / FLOPs may be None when not modelled."""
     g = a.get
     has = lambda k: bool(g(k))
+    if name.endswith('_f16'):                            # the fp16 twins (include/daft_exprt_hip.h): same kernels, same work
+        name = name[:-4]
     if name == 'dx_conv_gemm':
         rows = geom.rows(a['B'], a['N'], has('lens'))
         xb, yb, ab = (2 if a['x_bf16'] else 4), (2 if a['y_bf16'] else 4), (2 if a['aux_bf16'] else 4)
