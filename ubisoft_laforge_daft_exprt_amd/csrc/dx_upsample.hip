@@ -165,21 +165,43 @@ struct UpBwdArgs {
   int B, L, T;
 };
 
-// grid (ceil(T/TT), B), 256 threads.  LDS: g[TT][D+4] (dx_up tile), dw[L][TT], w[L][TT], inner[TT], xs[32][D]
+// four v_mfma_f32_16x16x4_f32 over 16 consecutive k: a / b = the lane's 4 consecutive k values (k = 4 (lane / 16) + e) of row (lane % 16)
+__device__ __forceinline__ f32x4 up_mma4(const float4& a, const float4& b, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, c, 0, 0, 0);
+  return c;
+}
+
+// grid (ceil(T/TT), B), 256 threads.  LDS: g[TT][D+4] (dx_up tile), dw[Lp][TT], w[Lp][TT+4], inner[256], and one region that holds the
+// symbol rows xs[32][D+4] during the first product and the transposed gradient tile gT[D][TT+4] during the second (Lp = L rounded up to 16).
+// Both products run on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32: exact fp32 multiply-add, so the f32 parity mode keeps its bar):
+//   dw[l][t] = sum_c xs[l][c] g[t][c]   (A = xs rows, B = g rows, k = c)        dxs[l][c] += sum_t w[l][t] g[t][c]   (A = w rows, B = gT rows, k = t)
+// As fp32 FMA loops over LDS operands they were 2.6 GFLOP of VALU work per launch behind two LDS reads per 4 FMAs: 99 us.
+// (Tried: one workgroup walking 4 consecutive frame tiles with the d(xs) tiles kept in registers, a quarter of the atomics: 71 -> 137 us.
+// The kernel is bound by the serial phases of ONE workgroup per tile, not by its atomics; fewer, longer workgroups made that worse.)
 template <int TT>
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const UpBwdArgs a) {
   constexpr int GLD = D + 4;
+  constexpr int WLD = TT + 4;
+  constexpr int DLD = TT + 1;                          // dw rows: odd stride (thread-per-symbol reads down a column)
   constexpr int XB = 32;
+  constexpr int NTT = TT / 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int Lp = (a.L + 15) & ~15;
   float* gt = smem;                                   // [TT][GLD]
-  float* dwt = gt + TT * GLD;                         // [L][TT]
-  float* wt = dwt + (size_t)a.L * TT;                 // [L][TT]
-  float* inner = wt + (size_t)a.L * TT;               // [256] scratch
-  float* xst = inner + 256;                           // [XB][D] symbol rows of the current block
-  const int b = blockIdx.y, t0 = blockIdx.x * TT;
-  const int tid = threadIdx.x;
+  float* dwt = gt + TT * GLD;                         // [Lp][DLD]
+  float* wt = dwt + (((size_t)Lp * DLD + 3) & ~(size_t)3);   // [Lp][WLD]
+  float* inner = wt + (size_t)Lp * WLD;               // [256] scratch
+  float* xst = inner + 256;                           // [XB][GLD] symbol rows of the current block, later gT [D][WLD]
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, g4 = (lane >> 4) * 4;
   const int len = a.lens[b];
   const float* xb = a.xs + (size_t)b * a.L * D;
+  const int nlt = (min(len, a.L) + 15) >> 4;
+  const int t0 = blockIdx.x * TT;
   // stage dx_up tile (zero beyond T) and the weight tile
   bool nonzero = false;
   for (int u = tid; u < TT * (D / 4); u += 256) {
@@ -191,85 +213,88 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const UpBwdArgs a) {
   }
   // frame tiles beyond the utterance carry an all-zero gradient (the decoder masks them): every term below is then zero
   if (!__syncthreads_or(nonzero)) return;
-  for (int u = tid; u < a.L * TT; u += 256) {
+  for (int u = tid; u < Lp * TT; u += 256) {
     const int l = u / TT, tt = u % TT;
-    wt[u] = (l < len && t0 + tt < a.T) ? a.weights[((size_t)b * a.L + l) * a.T + t0 + tt] : 0.f;
+    wt[l * WLD + tt] = (l < len && t0 + tt < a.T) ? a.weights[((size_t)b * a.L + l) * a.T + t0 + tt] : 0.f;
+    dwt[l * DLD + tt] = 0.f;                                     // symbol rows the first product does not reach (l >= len rounded up to 32)
   }
-  __syncthreads();
-  constexpr int LG = 256 / TT;
-  const int tt = tid % TT, lg = tid / TT;
-  // dw[l][t] = sum_c dxup[t][c] * xs[l][c].  The symbol rows go through LDS 32 at a time: read straight from global inside the
-  // dot product they were a dependent load per 8 FMAs on a CU that holds one workgroup (LDS), i.e. one wave per SIMD.
-  float inn = 0.f;
+  // ---- dw[l][t]: the symbol rows go through LDS 32 at a time; a 32-row block is 2 x NTT output tiles of 16 x 16, handed to the waves in turn
   for (int l0 = 0; l0 < len; l0 += XB) {
     __syncthreads();
     for (int u = tid; u < XB * (D / 4); u += 256) {
       const int l = u / (D / 4), q = u % (D / 4);
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (l0 + l < len) v = *reinterpret_cast<const float4*>(xb + (size_t)(l0 + l) * D + q * 4);
-      *reinterpret_cast<float4*>(xst + l * D + q * 4) = v;
+      *reinterpret_cast<float4*>(xst + l * GLD + q * 4) = v;
     }
     __syncthreads();
-    const int lend = min(XB, len - l0);
-    for (int l = lg; l < lend; l += LG) {
-      const float* xr = xst + l * D;                  // one row per wave-iteration: LDS broadcast
-      const float* gr = gt + tt * GLD;
-      float s = 0.f;
-#pragma unroll 8
-      for (int c = 0; c < D; c += 4) {
-        const float4 xv = *reinterpret_cast<const float4*>(xr + c);
-        const float4 gv = *reinterpret_cast<const float4*>(gr + c);
-        s = fmaf(xv.w, gv.w, fmaf(xv.z, gv.z, fmaf(xv.y, gv.y, fmaf(xv.x, gv.x, s))));
+    for (int tile = wave; tile < 2 * NTT; tile += 4) {
+      const int lt = tile / NTT, tt2 = tile - lt * NTT;
+      if (l0 + lt * 16 >= Lp) continue;
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc;   // two chains: a 16x16x4 MFMA waits for the previous one's result on the same accumulator
+      const float* ap = xst + (lt * 16 + r) * GLD + g4;
+      const float* bp = gt + (tt2 * 16 + r) * GLD + g4;
+#pragma unroll
+      for (int kb = 0; kb < D / 16; kb += 2) {
+        acc = up_mma4(*reinterpret_cast<const float4*>(ap + kb * 16), *reinterpret_cast<const float4*>(bp + kb * 16), acc);
+        acc1 = up_mma4(*reinterpret_cast<const float4*>(ap + kb * 16 + 16), *reinterpret_cast<const float4*>(bp + kb * 16 + 16), acc1);
       }
-      dwt[(size_t)(l0 + l) * TT + tt] = s;
-      inn += s * wt[(size_t)(l0 + l) * TT + tt];
+      acc += acc1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dwt[(size_t)(l0 + lt * 16 + g4 + e) * DLD + tt2 * 16 + r] = acc[e];     // D[m = 4 (lane / 16) + e][n = lane % 16]
     }
   }
-  inner[lg * TT + tt] = inn;
   __syncthreads();
-  if (lg == 0) {
+  // gT[c][t] for the second product (the symbol-row region is free now), and inner[t] = sum_l dw[l][t] w[l][t]
+  float* gT = xst;
+  for (int u = tid; u < TT * D; u += 256) {
+    const int tt = u / D, c = u - tt * D;
+    gT[c * WLD + tt] = gt[tt * GLD + c];
+  }
+  constexpr int LG = 256 / TT;
+  {
+    const int tt = tid % TT, lg = tid / TT;
+    float inn = 0.f;
+    for (int l = lg; l < len; l += LG) inn += dwt[(size_t)l * DLD + tt] * wt[l * WLD + tt];
+    inner[lg * TT + tt] = inn;
+  }
+  __syncthreads();
+  if (tid < TT) {
     float tot = 0.f;
-    for (int k = 0; k < LG; ++k) tot += inner[k * TT + tt];
-    inner[tt] = tot;
+    for (int k = 0; k < LG; ++k) tot += inner[k * TT + tid];
+    inner[tid] = tot;
   }
   __syncthreads();
   // d log p[l][t] = w (dw - inner[t]);  dsigma[l] += sum_t dlogp ((t+.5-mu)^2 / sigma^3 - 1/sigma)
-  // one wave per symbol l (4 at a time): lanes over frames
-  {
-    const int lane = tid & 63, wave = tid >> 6;
-    const float* mu = a.mu + (size_t)b * a.L;
-    const float* sg = a.sigma + (size_t)b * a.L;
-    for (int l = wave; l < len; l += 4) {
-      const float m = mu[l], sd = sg[l];
-      float s = 0.f;
-      for (int k = lane; k < TT; k += 64) {
-        const float w = wt[(size_t)l * TT + k];
-        const float dlp = w * (dwt[(size_t)l * TT + k] - inner[k]);
-        const float d = ((float)(t0 + k) + 0.5f) - m;
-        s += dlp * ((d * d) / (sd * sd * sd) - 1.f / sd);
-      }
-      s = dx_wave_sum(s);
-      if (lane == 0 && s != 0.f) atomicAdd(&a.dsigma[(size_t)b * a.L + l], s);
+  // thread per symbol, frames in a loop (a wave per symbol with lanes over the 32 frames left half the lanes idle and paid a 6-step wave
+  // reduction per symbol: ~9 k cycles of this workgroup's ~50 k)
+  for (int l = tid; l < len; l += 256) {
+    const float m = a.mu[(size_t)b * a.L + l], sd = a.sigma[(size_t)b * a.L + l];
+    const float i3 = 1.f / (sd * sd * sd), i1 = 1.f / sd;
+    float s = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < TT; ++k) {
+      const float dlp = wt[l * WLD + k] * (dwt[(size_t)l * DLD + k] - inner[k]);
+      const float d = ((float)(t0 + k) + 0.5f) - m;
+      s += dlp * ((d * d) * i3 - i1);
     }
+    if (s != 0.f) atomicAdd(&a.dsigma[(size_t)b * a.L + l], s);
   }
-  // dxs[l][c] += sum_t w[l][t] * dxup[t][c]; thread = channel x half of the symbols, four symbols at a time so that one
-  // g value feeds four FMAs and the weights are read as float4 (0.5 LDS reads per FMA instead of 2)
+  // ---- dxs[l][c] += sum_t w[l][t] g[t][c]: (Lp / 16) x 8 output tiles, k = TT
   {
-    const int c = tid & 127, lh = tid >> 7;
-    for (int l = lh * 4; l < len; l += 8) {
-      float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-      for (int k = 0; k < TT; k += 4) {
-        const float g0 = gt[k * GLD + c], g1 = gt[(k + 1) * GLD + c], g2 = gt[(k + 2) * GLD + c], g3 = gt[(k + 3) * GLD + c];
+    for (int tile = wave; tile < nlt * (D / 16); tile += 4) {
+      const int lt = tile / (D / 16), ct = tile - lt * (D / 16);
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* ap = wt + (lt * 16 + r) * WLD + g4;
+      const float* bp = gT + (ct * 16 + r) * WLD + g4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float4 w4 = *reinterpret_cast<const float4*>(wt + (size_t)min(l + j, a.L - 1) * TT + k);   // rows >= len hold zeros
-          s[j] = fmaf(w4.w, g3, fmaf(w4.z, g2, fmaf(w4.y, g1, fmaf(w4.x, g0, s[j]))));
-        }
+      for (int kb = 0; kb < TT / 16; ++kb)
+        acc = up_mma4(*reinterpret_cast<const float4*>(ap + kb * 16), *reinterpret_cast<const float4*>(bp + kb * 16), acc);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int l = lt * 16 + g4 + e;
+        if (l < len && acc[e] != 0.f) atomicAdd(&a.dxs[((size_t)b * a.L + l) * D + ct * 16 + r], acc[e]);
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (l + j < len && s[j] != 0.f) atomicAdd(&a.dxs[((size_t)b * a.L + l + j) * D + c], s[j]);
     }
   }
 }
@@ -331,7 +356,10 @@ __global__ __launch_bounds__(256) void upsample_sym_bwd_kernel(const SymBwdArgs 
 }
 
 template <int TT> size_t fwd_smem(int L) { return ((size_t)L * TT + (size_t)(256 / TT) * TT) * sizeof(float); }
-template <int TT> size_t bwd_smem(int L) { return ((size_t)TT * (D + 4) + 2 * (size_t)L * TT + 256 + 32 * D) * sizeof(float); }
+template <int TT> size_t bwd_smem(int L) {
+  const size_t Lp = (size_t)((L + 15) & ~15);
+  return ((size_t)TT * (D + 4) + ((Lp * (TT + 1) + 3) & ~(size_t)3) + Lp * (TT + 4) + 256 + std::max<size_t>(32 * (D + 4), (size_t)D * (TT + 4))) * sizeof(float);
+}
 
 template <int TT>
 int launch_fwd(const UpArgs& a, hipStream_t s) {
