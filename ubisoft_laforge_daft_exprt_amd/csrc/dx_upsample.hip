@@ -441,7 +441,10 @@ int dx_upsample_sym_bwd(const float* dxs_in, const float* dsigma, const float* x
   DX_REQUIRE(Dm == D && B > 0 && L > 0, "dx_upsample_sym_bwd: bad dims (D must be 128)");
   SymBwdArgs a{dxs_in, dsigma, xs, z, dur, lens, wd, bd, wr, dxs_out, dz, dwr, dbr, B, L};
   const long rows = (long)B * L;
-  hipLaunchKernelGGL(upsample_sym_bwd_kernel, dim3((int)std::min<long>((rows + 3) / 4, 1024)), dim3(256), 0, (hipStream_t)stream, a);
+  // every block ends in 129 atomics on the same 129 addresses (dwr, dbr): ~70 ns each when the blocks finish together, so the launch time
+  // follows the block count on one side and the rows per wave on the other (1024 / 256 / 128 / 64 blocks: 40 / 20 / 24 / 37 us)
+  static const int nblk_env = getenv("DX_SYM_BLOCKS") ? atoi(getenv("DX_SYM_BLOCKS")) : 256;
+  hipLaunchKernelGGL(upsample_sym_bwd_kernel, dim3((int)std::min<long>((rows + 3) / 4, nblk_env)), dim3(256), 0, (hipStream_t)stream, a);
   DX_LAUNCH_CHECK("dx_upsample_sym_bwd");
   return DX_OK;
 }
