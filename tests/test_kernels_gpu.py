@@ -409,6 +409,51 @@ def test_ff_pair_backward_layernorm_epilogue_equals_two_launches(ops, precision,
         ops.set_precision('f32')
 
 
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+@pytest.mark.parametrize('p_drop,use_film', [(0.0, True), (0.2, True), (0.2, False)])
+def test_ff_block_backward_equals_three_launches(ops, precision, p_drop, use_film):
+    """dx_ff_block_bwd == dx_ln_bwd (second LayerNorm) + dx_ff_pair (input-gradient pair, accumulate) + dx_ln_bwd (first LayerNorm), same
+    seeds: dz1, both 16-bit gradient copies, the hidden gradient, the affine and FiLM gradients; lengths on tile edges and halo rows."""
+    ops.set_precision(precision)
+    try:
+        h16 = ops.hidden_dtype()
+        B, N, Fc = 5, 300, 1024
+        lens = lens_tensor([300, 252, 126, 127, 40])
+        valid = (torch.arange(N, device=DEV)[None, :] < lens[:, None])
+        vf = valid[:, :, None].float()
+        w1 = randn(Fc, 128, 3, seed=2, scale=1 / math.sqrt(384))
+        w2 = randn(128, Fc, 3, seed=4, scale=1 / math.sqrt(3 * Fc))
+        p1, p2 = ops.PackedWeight(w1), ops.PackedWeight(w2)
+        x = (randn(B, N, 128, seed=1) * vf).to(h16)
+        h = ops.conv_gemm(x, p1, randn(Fc, seed=3, scale=0.1), relu=True, lens=lens, halo=1, out_dtype=h16)
+        dy2 = randn(B, N, 128, seed=5) * vf
+        z2, z1 = randn(B, N, 128, seed=6), randn(B, N, 128, seed=7)
+        st = lambda z: (z.mean(dim=2), 1.0 / torch.sqrt(z.var(dim=2, unbiased=False) + 1e-5))
+        (m2, r2), (m1, r1) = st(z2), st(z1)
+        l2w, l2b = 1 + 0.1 * randn(128, seed=8), randn(128, seed=9, scale=0.1)
+        l1w, l1b = 1 + 0.1 * randn(128, seed=10), randn(128, seed=11, scale=0.1)
+        film = randn(B, 256, seed=12) if use_film else None
+        # three launches
+        a = ops.ln_bwd(dy2, z2, m2, r2, l2w, l2b, film, lens, want_da=p_drop > 0, seed_pre=71, p_pre=p_drop, shadow=True)
+        dz2, dw2, db2, dfilm0, dff0 = a[0], a[2], a[3], a[4], a[5]
+        dy1, dh0 = ops.ff_pair(dff0, p1, p2, None, None, lens, backward=True, aux=h, out=dz2, accumulate=True)
+        b_ = ops.ln_bwd(dy1, z1, m1, r1, l1w, l1b, None, lens, want_da=p_drop > 0, seed_pre=72, p_pre=p_drop, shadow=True)
+        dz1_0, dw1_0, db1_0, dg1_0 = b_[0], b_[2], b_[3], b_[5]
+        # one launch
+        dz1, dh, dg1, dg2, dfilm, dw2n, db2n, dw1n, db1n = ops.ff_block_bwd(dy2, z2, m2, r2, l2w, l2b, film, p1, p2, lens, h, z1, m1, r1, l1w, l1b,
+                                                                            seed2=71, p2=p_drop, seed1=72, p1=p_drop)
+        # the prologue sums a row's channels in another order than dx_ln_bwd: equal up to one 16-bit rounding step of the copy
+        assert rel_err(dg2.float(), dff0.float()) < 1e-2 and float(dg2[~valid].float().abs().max()) == 0.0
+        assert rel_err(dh.float(), dh0.float()) < 2e-2
+        assert rel_err(dz1, dz1_0) < 1e-3 and float(dz1[~valid].abs().max()) == 0.0       # (downstream of the 16-bit copy's rounding step)
+        assert rel_err(dg1.float(), dg1_0.float()) < 1e-2 and float(dg1[~valid].float().abs().max()) == 0.0
+        assert rel_err(dw2n, dw2) < 1e-4 and rel_err(db2n, db2) < 1e-4 and rel_err(dw1n, dw1_0) < 1e-3 and rel_err(db1n, db1_0) < 1e-3
+        if use_film:
+            assert rel_err(dfilm, dfilm0) < 1e-4
+    finally:
+        ops.set_precision('f32')
+
+
 @pytest.mark.parametrize('with_pm', [True, False])
 def test_film_affine_forward_backward_vs_torch(ops, with_pm):
     """FilmAffineFn (StyleAdapter tail, model.py:779-800) against the element-wise torch formulation, incl. blocks that receive no gradient."""

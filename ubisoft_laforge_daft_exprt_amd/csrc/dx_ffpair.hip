@@ -56,6 +56,14 @@ struct FFPairArgs {
   // GEMMs (lnb_dg) and the affine gradients (lnb_dw / lnb_db, atomics) -- dx_ln_bwd with C = 128, no FiLM, halo 0, done while the tile is in LDS
   const float* lnb_z; const float* lnb_mean; const float* lnb_rstd; const float* lnb_w; const float* lnb_b;
   dx_h16* lnb_dg; float* lnb_dw; float* lnb_db;
+  // optional LayerNorm-BACKWARD prologue of the input-gradient pair (lnp_w != null; needs the epilogue above): X is not read; the tile's
+  // rows of d(loss)/d(y2) (lnp_dy) go through the backward of the block's SECOND LayerNorm on their way into LDS: dz2 -> Y (the residual
+  // gradient the epilogue then adds to), dropout(dz2) as 16 bits -> the LDS tile and lnp_dg (for the weight gradient of the second conv),
+  // affine / FiLM gradients -> lnp_dw, lnp_db, lnp_dfilm (atomics).  dx_ln_bwd with C = 128, FiLM optional, halo 0.
+  const float* lnp_dy; const float* lnp_z; const float* lnp_mean; const float* lnp_rstd; const float* lnp_w; const float* lnp_b;
+  const float* lnp_film; int lnp_ld_film;
+  dx_h16* lnp_dg; float* lnp_dw; float* lnp_db; float* lnp_dfilm; int lnp_ld_dfilm;
+  unsigned long long lnp_seed; unsigned lnp_thresh; float lnp_inv_keep;
   unsigned long long* stamps;        // diagnostic builds (-DDX_FFPAIR_STAMPS, tools/ffpair_stamps.py) only: [workgroup][role][16] s_memtime values
 };
 
@@ -184,9 +192,15 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
       *reinterpret_cast<f32x4*>(a.H + ((size_t)b * a.N + n0 + row) * a.ldh + q * 8) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (a.lnb_w)
-      for (int u = tid; u < rows * 16; u += 512) {        // 16-bit gradient copy: 16 x 16 bytes per row
+      for (int u = tid; u < rows * 16; u += 512) {        // 16-bit gradient copies: 16 x 16 bytes per row
         const int row = u >> 4, q = u & 15;
         *reinterpret_cast<f32x4*>(a.lnb_dg + ((size_t)b * a.N + n0 + row) * 128 + q * 8) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.lnp_w) *reinterpret_cast<f32x4*>(a.lnp_dg + ((size_t)b * a.N + n0 + row) * 128 + q * 8) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    if (a.lnp_w)                                          // Y was nobody's output before this launch: the residual gradient of padding is zero
+      for (int u = tid; u < rows * 32; u += 512) {
+        const int row = u >> 5, q = u & 31;
+        *reinterpret_cast<f32x4*>(a.Y + ((size_t)b * a.N + n0 + row) * a.ldy + q * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     if (!a.accumulate)
       for (int u = tid; u < rows * 32; u += 512) {
@@ -198,6 +212,116 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
   }
 
   const int NL = a.rows_exist ? a.rows_exist[b] : a.N;   // rows of this batch row that exist for the two convolutions
+  if (a.lnp_w) {
+    // ---- LayerNorm-backward prologue: the activation tile is COMPUTED (16 lanes x 8 channels per row, 32 rows per pass) ------------
+    const int q = tid & 15;
+    const int len_b = a.lens ? a.lens[b] : a.N;
+    float wv[8], bv[8], fg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      wv[e] = a.lnp_w[q * 8 + e]; bv[e] = a.lnp_b[q * 8 + e];
+      fg[e] = a.lnp_film ? a.lnp_film[(size_t)b * a.lnp_ld_film + q * 8 + e] : 1.f;
+    }
+    const unsigned long long seed = a.lnp_seed + (a.seed_offset ? *a.seed_offset : 0ull);
+    float gw[8], gb[8], gfg[8], gfb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gw[e] = gb[e] = gfg[e] = gfb[e] = 0.f;
+    f32x4 dyv[5][2], zv[5][2];
+    float muv[5], rsv[5];
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {                    // all global reads first
+      const int row = (tid >> 4) + it * 32, n = n0 - 2 + row;
+      const bool valid = row < FP_HR && n >= 0 && n < len_b && n < NL;
+      const size_t grow = (size_t)b * a.N + n;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        dyv[it][hh] = valid ? *reinterpret_cast<const f32x4*>(a.lnp_dy + grow * 128 + q * 8 + hh * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        zv[it][hh] = valid ? *reinterpret_cast<const f32x4*>(a.lnp_z + grow * 128 + q * 8 + hh * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      muv[it] = valid ? a.lnp_mean[grow] : 0.f;
+      rsv[it] = valid ? a.lnp_rstd[grow] : 0.f;
+    }
+    FP_WLOAD(0, 0) FP_WLOAD(1, 1) FP_WLOAD(2, 2) FP_WLOAD(3, 3)      // first weight fragments: in flight beside the row arithmetic
+#pragma unroll
+    for (int it = 0; it < 5; ++it) {
+      const int row = (tid >> 4) + it * 32, n = n0 - 2 + row;
+      const bool inb = row < FP_HR && n >= 0 && n < a.N;
+      const bool owned = inb && row >= 2 && row < 2 + FP_TOK;         // the 126 rows this workgroup writes and sums (halo rows: only the LDS tile)
+      const bool ownvalid = owned && n < len_b;
+      const size_t grow = (size_t)b * a.N + n;
+      float dz[8];
+      float s1 = 0.f, s2 = 0.f, g[8], xh[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float z = zv[it][e >> 2][e & 3];
+        float d = dyv[it][e >> 2][e & 3];
+        xh[e] = (z - muv[it]) * rsv[it];
+        const float ln = xh[e] * wv[e] + bv[e];
+        if (ownvalid) { gfg[e] += d * ln; gfb[e] += d; }
+        d *= fg[e];
+        if (ownvalid) { gw[e] += d * xh[e]; gb[e] += d; }
+        g[e] = d * wv[e];
+        s1 += g[e]; s2 += g[e] * xh[e];
+      }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+      s1 *= (1.0f / 128); s2 *= (1.0f / 128);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dz[e] = rsv[it] * (g[e] - s1 - xh[e] * s2);
+      if (owned) {
+        *reinterpret_cast<f32x4*>(a.Y + grow * a.ldy + q * 8) = f32x4{dz[0], dz[1], dz[2], dz[3]};
+        *reinterpret_cast<f32x4*>(a.Y + grow * a.ldy + q * 8 + 4) = f32x4{dz[4], dz[5], dz[6], dz[7]};
+      }
+      if (a.lnp_thresh) {
+        float f[8];
+        dx_dropout_scale4(seed, (unsigned long long)grow * 128 + q * 8, a.lnp_thresh, a.lnp_inv_keep, f);
+        dx_dropout_scale4(seed, (unsigned long long)grow * 128 + q * 8 + 4, a.lnp_thresh, a.lnp_inv_keep, f + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dz[e] *= f[e];
+      }
+      bf16x8 h8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) h8[e] = (dx_h16)dz[e];
+      const f32x4 hv = __builtin_bit_cast(f32x4, h8);
+      if (owned) *reinterpret_cast<f32x4*>(a.lnp_dg + grow * 128 + q * 8) = hv;
+      if (row < FP_HR) *reinterpret_cast<f32x4*>(Xs + (q >> 3) * (FP_HR * 128) + fp_lds_off(row, q & 7)) = hv;
+    }
+    // affine / FiLM gradients: the four rows of a wave fold by shuffles, the eight waves through LDS (the first hidden image is still
+    // unused), one atomic per channel and quantity per workgroup
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int off = 16; off < 64; off <<= 1) {
+        gw[e] += __shfl_xor(gw[e], off, 64); gb[e] += __shfl_xor(gb[e], off, 64);
+        gfg[e] += __shfl_xor(gfg[e], off, 64); gfb[e] += __shfl_xor(gfb[e], off, 64);
+      }
+    }
+    float* const red = reinterpret_cast<float*>(Hs0);               // [8 waves][4 quantities][128]: 16 KB, below the image's zero rows
+    if (lane < 16) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(wave * 4 + 0) * 128 + q * 8 + e] = gw[e]; red[(wave * 4 + 1) * 128 + q * 8 + e] = gb[e];
+        red[(wave * 4 + 2) * 128 + q * 8 + e] = gfg[e]; red[(wave * 4 + 3) * 128 + q * 8 + e] = gfb[e];
+      }
+    }
+    __syncthreads();
+    {
+      const int quant = tid >> 7, c = tid & 127;
+      float t = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) t += red[(w8 * 4 + quant) * 128 + c];
+      if (t != 0.f) {
+        if (quant == 0) atomicAdd(&a.lnp_dw[c], t);
+        else if (quant == 1) atomicAdd(&a.lnp_db[c], t);
+        else if (a.lnp_dfilm) atomicAdd(&a.lnp_dfilm[(size_t)b * a.lnp_ld_dfilm + (quant == 3 ? 128 : 0) + c], t);
+      }
+    }
+    __syncthreads();                                     // the scratch is read: the hidden image may be written
+    if (tid < 64) {
+      const int img = tid >> 5, rr = 128 + ((tid >> 4) & 1), qq = tid & 15;
+      *reinterpret_cast<f32x4*>((img ? Hs1 : Hs0) + (qq >> 3) * (FP_HR * 128) + fp_lds_off(rr, qq & 7)) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  } else
   // ---- stage the activation tile: rows p = 0..129 <-> n = n0 - 2 + p, zero outside [0, NL) --------------------------------
   {
     f32x4 xr[5];
@@ -572,8 +696,8 @@ static int ff_pair_launch(const void* X, int ldx, const void* Wa, const void* Wb
                           const float* ln_res, const float* ln_w, const float* ln_b, const float* film, int ld_film,
                           float* ln_y, float* ln_mean, float* ln_rstd, unsigned long long seed_pre, float p_pre, const unsigned long long* seed_offset,
                           const float* lnb_z, const float* lnb_mean, const float* lnb_rstd, const float* lnb_w, const float* lnb_b,
-                          void* lnb_dg, float* lnb_dw, float* lnb_db, void* stream) {
-  DX_REQUIRE(X && Wa && Wb && H && Y, "dx_ff_pair: null pointer");
+                          void* lnb_dg, float* lnb_dw, float* lnb_db, const FFPairArgs* prologue, void* stream) {
+  DX_REQUIRE((X || prologue) && Wa && Wb && H && Y, "dx_ff_pair: null pointer");
   if (ln_w) {
     DX_REQUIRE(relu_mid && !accumulate && lens && skip_halo >= 0 && ldy == 128, "dx_ff_pair_ln: forward pair, no accumulate, lens, dense Z");
     DX_REQUIRE(ln_res && ln_b && ln_y && ln_mean && ln_rstd, "dx_ff_pair_ln: null pointer");
@@ -590,12 +714,25 @@ static int ff_pair_launch(const void* X, int ldx, const void* Wa, const void* Wb
   DX_REQUIRE(!aux || (ld_aux >= F && (ld_aux % 4) == 0), "dx_ff_pair: bad ld_aux");
   DX_REQUIRE((aux != nullptr) != (relu_mid != 0), "dx_ff_pair: exactly one of relu_mid (forward) and aux (backward) must be given");
   DX_REQUIRE(skip_halo < 0 || lens, "dx_ff_pair: skip_halo needs lens");
+  if (prologue) {
+    DX_REQUIRE(lnb_w && prologue->lnp_dy && prologue->lnp_z && prologue->lnp_mean && prologue->lnp_rstd && prologue->lnp_w && prologue->lnp_b &&
+               prologue->lnp_dg && prologue->lnp_dw && prologue->lnp_db, "dx_ff_block_bwd: null pointer");
+    DX_REQUIRE((prologue->lnp_film == nullptr) == (prologue->lnp_dfilm == nullptr), "dx_ff_block_bwd: film and dfilm must come together");
+    DX_REQUIRE(((uintptr_t)prologue->lnp_dy % 16) == 0 && ((uintptr_t)prologue->lnp_z % 16) == 0 && ((uintptr_t)prologue->lnp_dg % 16) == 0,
+               "dx_ff_block_bwd: pointers must be 16-byte aligned");
+  }
   DX_REQUIRE(((uintptr_t)X % 16) == 0 && ((uintptr_t)Wa % 16) == 0 && ((uintptr_t)Wb % 16) == 0 && ((uintptr_t)H % 16) == 0 &&
              ((uintptr_t)Y % 16) == 0 && ((uintptr_t)aux % 8) == 0, "dx_ff_pair: pointers must be 16-byte aligned");
   FFPairArgs a{(const dx_h16*)X, ldx, (const dx_h16*)Wa, (const dx_h16*)Wb, bias_a, bias_b, (const dx_h16*)aux, ld_aux,
                (dx_h16*)H, ldh, Y, ldy, B, N, F, accumulate, lens, skip_halo, rows_exist,
                ln_res, ln_w, ln_b, film, ld_film, ln_y, ln_mean, ln_rstd, seed_pre, (unsigned)lrintf(p_pre * 65536.f), 1.f / (1.f - p_pre), seed_offset,
-               lnb_z, lnb_mean, lnb_rstd, lnb_w, lnb_b, (dx_h16*)lnb_dg, lnb_dw, lnb_db, nullptr};
+               lnb_z, lnb_mean, lnb_rstd, lnb_w, lnb_b, (dx_h16*)lnb_dg, lnb_dw, lnb_db};
+  if (prologue) {
+    a.lnp_dy = prologue->lnp_dy; a.lnp_z = prologue->lnp_z; a.lnp_mean = prologue->lnp_mean; a.lnp_rstd = prologue->lnp_rstd;
+    a.lnp_w = prologue->lnp_w; a.lnp_b = prologue->lnp_b; a.lnp_film = prologue->lnp_film; a.lnp_ld_film = prologue->lnp_ld_film;
+    a.lnp_dg = prologue->lnp_dg; a.lnp_dw = prologue->lnp_dw; a.lnp_db = prologue->lnp_db; a.lnp_dfilm = prologue->lnp_dfilm;
+    a.lnp_ld_dfilm = prologue->lnp_ld_dfilm; a.lnp_seed = prologue->lnp_seed; a.lnp_thresh = prologue->lnp_thresh; a.lnp_inv_keep = prologue->lnp_inv_keep;
+  }
 #ifdef DX_FFPAIR_STAMPS
   a.stamps = g_ffpair_stamps;
 #endif
@@ -620,7 +757,7 @@ int dx_ff_pair(const void* X, int ldx, const void* Wa, const void* Wb, const flo
                int B, int N, int F, int relu_mid, int accumulate, const int* lens, int skip_halo, const int* rows_exist, void* stream) {
   return ff_pair_launch(X, ldx, Wa, Wb, bias_a, bias_b, aux, ld_aux, H, ldh, Y, ldy, B, N, F, relu_mid, accumulate, lens, skip_halo, rows_exist,
                         nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0ull, 0.f, nullptr,
-                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 // The forward pair with the block's second LayerNorm folded into its epilogue:
@@ -633,7 +770,7 @@ int dx_ff_pair_ln(const void* X, int ldx, const void* Wa, const void* Wb, const 
   DX_REQUIRE(ln_w != nullptr, "dx_ff_pair_ln: null pointer");
   return ff_pair_launch(X, ldx, Wa, Wb, bias_a, bias_b, nullptr, 0, H, ldh, Z, 128, B, N, F, 1, 0, lens, skip_halo, rows_exist,
                         res, ln_w, ln_b, film, ld_film, Yln, mean, rstd, (unsigned long long)seed_pre, p_pre, (const unsigned long long*)seed_offset,
-                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 // The input-gradient pair with the backward of the block's FIRST LayerNorm folded into its epilogue:
@@ -647,7 +784,31 @@ int dx_ff_pair_lnbwd(const void* X, int ldx, const void* Wa, const void* Wb, con
   DX_REQUIRE(ln_w != nullptr, "dx_ff_pair_lnbwd: null pointer");
   return ff_pair_launch(X, ldx, Wa, Wb, nullptr, nullptr, aux, ld_aux, H, ldh, Y, 128, B, N, F, 0, 1, lens, skip_halo, nullptr,
                         nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, (unsigned long long)seed_pre, p_pre, (const unsigned long long*)seed_offset,
-                        z, mean, rstd, ln_w, ln_b, DG, dw, db, stream);
+                        z, mean, rstd, ln_w, ln_b, DG, dw, db, nullptr, stream);
+}
+
+// The whole conv feed-forward half of an FFT block's backward in ONE launch:
+//   [prologue] dz2 = LayerNorm2-backward(dY2; z2, mean2, rstd2, w2, film)  -> Y;  dropout(dz2) (16 bits) -> the LDS tile and DG2; dw2 / db2 / dfilm +=
+//   [pair]     conv2^T -> ReLU mask (aux) -> conv1^T, hidden gradient -> H
+//   [epilogue] dz1 = LayerNorm1-backward(Y + pair result; z1, mean1, rstd1, w1) -> Y;  dropout(dz1) (16 bits) -> DG1;  dw1 / db1 +=
+// i.e. dx_ln_bwd (C = 128, FiLM optional, halo 0) + dx_ff_pair (input-gradient pair) + dx_ln_bwd (no FiLM) of model.py:225-233 / :206-217 /
+// :188-191 backward.  Y is an OUTPUT here (nothing is read from it); dfilm (optional, [B][ld_dfilm >= 256]) accumulates like dw / db.
+int dx_ff_block_bwd(const float* dY2, const float* z2, const float* mean2, const float* rstd2, const float* ln2_w, const float* ln2_b,
+                    const float* film, int ld_film, void* DG2, float* dw2, float* db2, float* dfilm, int ld_dfilm, uint64_t seed2, float p2,
+                    const void* Wa, const void* Wb, const void* aux, int ld_aux, void* H, int ldh, float* Y,
+                    int B, int N, int F, const int* lens, int skip_halo,
+                    const float* z1, const float* mean1, const float* rstd1, const float* ln1_w, const float* ln1_b, void* DG1, float* dw1, float* db1,
+                    uint64_t seed1, float p1, const uint64_t* seed_offset, void* stream) {
+  DX_REQUIRE(ln1_w != nullptr && ln2_w != nullptr, "dx_ff_block_bwd: null pointer");
+  DX_REQUIRE(p2 >= 0.f && p2 < 1.f, "dx_ff_block_bwd: dropout p out of range");
+  DX_REQUIRE(!film || (ld_film >= 256 && ld_dfilm >= 256), "dx_ff_block_bwd: ld_film / ld_dfilm too small");
+  FFPairArgs pro{};
+  pro.lnp_dy = dY2; pro.lnp_z = z2; pro.lnp_mean = mean2; pro.lnp_rstd = rstd2; pro.lnp_w = ln2_w; pro.lnp_b = ln2_b;
+  pro.lnp_film = film; pro.lnp_ld_film = ld_film; pro.lnp_dg = (dx_h16*)DG2; pro.lnp_dw = dw2; pro.lnp_db = db2; pro.lnp_dfilm = dfilm;
+  pro.lnp_ld_dfilm = ld_dfilm; pro.lnp_seed = (unsigned long long)seed2; pro.lnp_thresh = (unsigned)lrintf(p2 * 65536.f); pro.lnp_inv_keep = 1.f / (1.f - p2);
+  return ff_pair_launch(nullptr, 128, Wa, Wb, nullptr, nullptr, aux, ld_aux, H, ldh, Y, 128, B, N, F, 0, 1, lens, skip_halo, nullptr,
+                        nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, (unsigned long long)seed1, p1, (const unsigned long long*)seed_offset,
+                        z1, mean1, rstd1, ln1_w, ln1_b, DG1, dw1, db1, &pro, stream);
 }
 
 }  // extern "C"

@@ -209,13 +209,24 @@ class FFTBlockFn(torch.autograd.Function):
         g = sk.get
         sh = ops.gemm_shadow(prec)
         so = ctx.seed_offset
-        r2 = ops.ln_bwd(dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, L, want_da=p_conv > 0, seed_pre=s_ln2, seed_offset=so, prec=prec,
-                        p_pre=p_conv, arena=arena, w_sink=g('ln2_w'), b_sink=g('ln2_b'), shadow=sh)
-        dz2, da2, dln2_w, dln2_b, dfilm = r2[:5]
-        dff = r2[5] if sh else (da2 if da2 is not None else dz2)      # gradient w.r.t. the conv2 output, as the GEMMs read it
-        dc2_w, dc2_b = ops.conv_wgrad(dff, h, packs['c2'], L, 0, arena=arena, w_sink=g('c2_w'), b_sink=g('c2_b'), prec=prec, defer=True)
         ln1_done = None
-        if ctx.fused and ops._FF_LNBWD and sh and dz2.is_contiguous():
+        whole = ctx.fused and ops._FF_LNBWD and ops._FF_BLOCK_BWD and sh and (film is None or film.stride(-1) == 1)
+        if whole:
+            # LayerNorm2-backward (prologue) -> conv2^T -> ReLU mask -> conv1^T -> LayerNorm1-backward (epilogue): ONE launch
+            (dz1_, dh, dproj_, dff, dfilm, dln2_w, dln2_b, dl1w, dl1b) = ops.ff_block_bwd(
+                dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, packs['c1'], packs['c2'], L, h, z1, mean1, rstd1, ln1_w, ln1_b,
+                seed2=s_ln2, p2=p_conv, seed1=s_ln1, p1=p_attn, seed_offset=so, prec=prec, arena=arena,
+                sinks={'ln2_w': g('ln2_w'), 'ln2_b': g('ln2_b'), 'ln1_w': g('ln1_w'), 'ln1_b': g('ln1_b')})
+            ln1_done = (dz1_, dh, dproj_, dl1w, dl1b)
+        else:
+            r2 = ops.ln_bwd(dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, L, want_da=p_conv > 0, seed_pre=s_ln2, seed_offset=so, prec=prec,
+                            p_pre=p_conv, arena=arena, w_sink=g('ln2_w'), b_sink=g('ln2_b'), shadow=sh)
+            dz2, da2, dln2_w, dln2_b, dfilm = r2[:5]
+            dff = r2[5] if sh else (da2 if da2 is not None else dz2)      # gradient w.r.t. the conv2 output, as the GEMMs read it
+        dc2_w, dc2_b = ops.conv_wgrad(dff, h, packs['c2'], L, 0, arena=arena, w_sink=g('c2_w'), b_sink=g('c2_b'), prec=prec, defer=True)
+        if whole:
+            pass
+        elif ctx.fused and ops._FF_LNBWD and sh and dz2.is_contiguous():
             # ... and the backward of the first LayerNorm on the output tile while it is in LDS: dz2's buffer comes back holding dz1
             ln1_done = ops.ff_pair_lnbwd(dff, packs['c1'], packs['c2'], L, h, dz2, z1, mean1, rstd1, ln1_w, ln1_b, seed_pre=s_ln1, p_pre=p_attn,
                                          seed_offset=so, prec=prec, arena=arena, w_sink=g('ln1_w'), b_sink=g('ln1_b'))

@@ -76,6 +76,11 @@ def price(name, a, geom: Geometry):
         F = a['F']
         byt = rows * (128 * 2 + 2 * F * 2 + 128 * 4 * 3 + 128 * 2 + 8) + 2 * 3 * 128 * F * 2
         return 'ff_pair_kernel<bwd>', 'mfma', 2.0 * 2 * 3 * 128 * F * rows, byt
+    if name == 'dx_ff_block_bwd':                        # LN2-backward prologue + input-gradient pair + LN1-backward epilogue
+        rows = geom.rows(a['B'], a['N'], has('lens'))
+        F = a['F']
+        byt = rows * (2 * 128 * 4 + 2 * 128 * 4 + 2 * 128 * 2 + 2 * F * 2 + 128 * 4 + 16) + 2 * 3 * 128 * F * 2   # dY2, z2, z1 read; dz2 + dz1 written; two 16-bit copies; aux + H
+        return 'ff_pair_kernel<bwd>', 'mfma', 2.0 * 2 * 3 * 128 * F * rows, byt
     if name == 'dx_conv_wgrad':
         rows = geom.rows(a['B'], a['N'], has('lens'))
         byt = rows * (a['Cout'] * (2 if a['dy_bf16'] else 4) + a['Cin'] * (2 if a['x_bf16'] else 4)) + a['taps'] * a['Cin'] * a['Cout'] * 4
