@@ -118,13 +118,15 @@ int dx_ff_pair_lnbwd(const void* X, int ldx, const void* Wa, const void* Wb, con
  * its epilogue.  dY2 [B][N][128] fp32 = d(loss)/d(block output); z2 / mean2 / rstd2 / ln2_* / film / seed2 / p2 and z1 / ... / seed1 / p1:
  * the arguments of the two dx_ln_bwd calls it replaces (C = 128, halo 0); Wa / Wb / aux / H / lens / skip_halo: those of dx_ff_pair
  * (input-gradient pair).  Outputs: Y = dz1 (fp32, the residual gradient for the attention half), DG1 = dropout(dz1) and DG2 = dropout(dz2)
- * as 16 bits (operands of the out-projection's and the second conv's backward GEMMs), H = the hidden gradient; dw* / db* / dfilm accumulate. */
+ * as 16 bits (operands of the out-projection's and the second conv's backward GEMMs), H = the hidden gradient; dw* / db* / dfilm accumulate.
+ * Wout_bwd / DATT (optional, together): the backward pack of the attention out-projection's (128, 128) weight and a 16-bit [B][N][128]
+ * output: the epilogue then also computes DATT = DG1 x W_out, the input gradient of the out-projection (what dx_attention_bwd takes as dctx). */
 int dx_ff_block_bwd(const float* dY2, const float* z2, const float* mean2, const float* rstd2, const float* ln2_w, const float* ln2_b,
                     const float* film, int ld_film, void* DG2, float* dw2, float* db2, float* dfilm, int ld_dfilm, uint64_t seed2, float p2,
                     const void* Wa, const void* Wb, const void* aux, int ld_aux, void* H, int ldh, float* Y,
                     int B, int N, int F, const int* lens, int skip_halo,
                     const float* z1, const float* mean1, const float* rstd1, const float* ln1_w, const float* ln1_b, void* DG1, float* dw1, float* db1,
-                    uint64_t seed1, float p1, const uint64_t* seed_offset, void* stream);
+                    uint64_t seed1, float p1, const void* Wout_bwd, void* DATT, const uint64_t* seed_offset, void* stream);
 /* out[c] += sum_rows X[row][c]   (bias gradients) */
 int dx_colsum(const void* X, int ldx, float* out, long rows, int C, int x_bf16, void* stream);
 

@@ -440,8 +440,12 @@ def test_ff_block_backward_equals_three_launches(ops, precision, p_drop, use_fil
         b_ = ops.ln_bwd(dy1, z1, m1, r1, l1w, l1b, None, lens, want_da=p_drop > 0, seed_pre=72, p_pre=p_drop, shadow=True)
         dz1_0, dw1_0, db1_0, dg1_0 = b_[0], b_[2], b_[3], b_[5]
         # one launch
-        dz1, dh, dg1, dg2, dfilm, dw2n, db2n, dw1n, db1n = ops.ff_block_bwd(dy2, z2, m2, r2, l2w, l2b, film, p1, p2, lens, h, z1, m1, r1, l1w, l1b,
-                                                                            seed2=71, p2=p_drop, seed1=72, p1=p_drop)
+        wo = randn(128, 128, seed=13, scale=0.09)
+        po = ops.PackedWeight(wo)
+        dz1, dh, dg1, dg2, dfilm, dw2n, db2n, dw1n, db1n, datt = ops.ff_block_bwd(dy2, z2, m2, r2, l2w, l2b, film, p1, p2, lens, h, z1, m1, r1, l1w, l1b,
+                                                                                  seed2=71, p2=p_drop, seed1=72, p1=p_drop, out_pack=po)
+        datt0 = ops.conv_gemm(dg1, po, None, transpose=True, lens=lens, halo=0, out_dtype=h16)      # the launch it replaces, on the same operand
+        assert rel_err(datt.float(), datt0.float()) < 1e-2 and float(datt[~valid].float().abs().max()) == 0.0
         # the prologue sums a row's channels in another order than dx_ln_bwd: equal up to one 16-bit rounding step of the copy
         assert rel_err(dg2.float(), dff0.float()) < 1e-2 and float(dg2[~valid].float().abs().max()) == 0.0
         assert rel_err(dh.float(), dh0.float()) < 2e-2

@@ -56,6 +56,9 @@ struct FFPairArgs {
   // GEMMs (lnb_dg) and the affine gradients (lnb_dw / lnb_db, atomics) -- dx_ln_bwd with C = 128, no FiLM, halo 0, done while the tile is in LDS
   const float* lnb_z; const float* lnb_mean; const float* lnb_rstd; const float* lnb_w; const float* lnb_b;
   dx_h16* lnb_dg; float* lnb_dw; float* lnb_db;
+  // ... optionally followed by the input-gradient GEMM of the attention out-projection on the same tile: DATT = lnb_dg x W_out
+  // (lnb_wt: the backward pack of the (128, 128) out-projection weight; lnb_datt: 16-bit [B][N][128], what the attention backward reads as dctx)
+  const dx_h16* lnb_wt; dx_h16* lnb_datt;
   // optional LayerNorm-BACKWARD prologue of the input-gradient pair (lnp_w != null; needs the epilogue above): X is not read; the tile's
   // rows of d(loss)/d(y2) (lnp_dy) go through the backward of the block's SECOND LayerNorm on their way into LDS: dz2 -> Y (the residual
   // gradient the epilogue then adds to), dropout(dz2) as 16 bits -> the LDS tile and lnp_dg (for the weight gradient of the second conv),
@@ -196,6 +199,7 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
         const int row = u >> 4, q = u & 15;
         *reinterpret_cast<f32x4*>(a.lnb_dg + ((size_t)b * a.N + n0 + row) * 128 + q * 8) = f32x4{0.f, 0.f, 0.f, 0.f};
         if (a.lnp_w) *reinterpret_cast<f32x4*>(a.lnp_dg + ((size_t)b * a.N + n0 + row) * 128 + q * 8) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.lnb_wt) *reinterpret_cast<f32x4*>(a.lnb_datt + ((size_t)b * a.N + n0 + row) * 128 + q * 8) = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     if (a.lnp_w)                                          // Y was nobody's output before this launch: the residual gradient of padding is zero
       for (int u = tid; u < rows * 32; u += 512) {
@@ -638,6 +642,16 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
       bf16x4 h4;
       h4[0] = (dx_h16)dz[0]; h4[1] = (dx_h16)dz[1]; h4[2] = (dx_h16)dz[2]; h4[3] = (dx_h16)dz[3];
       *reinterpret_cast<bf16x4*>(a.lnb_dg + grow * 128 + s * 4) = h4;
+      // the same 16-bit row, in place over the fp32 row it came from (this half wave has read all of it), for the GEMM below:
+      // 16 slots of 8 channels, XOR-swizzled by the row
+      if (a.lnb_wt) *reinterpret_cast<bf16x4*>(stage + row * 512 + (((s >> 1) ^ (row & 15)) << 4) + ((s & 1) << 3)) = h4;
+    }
+    if (a.lnb_wt) {                                     // rows this tile does not own (beyond N): zero operands
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int row = (tid >> 5) + k * 16;
+        if (row >= len_cols) *reinterpret_cast<uint2*>(stage + row * 512 + (((s >> 1) ^ (row & 15)) << 4) + ((s & 1) << 3)) = make_uint2(0u, 0u);
+      }
     }
     // affine gradients: 16 row groups x 128 channels fold through LDS (behind the staging tile), one atomic per channel per workgroup
     float* const red = reinterpret_cast<float*>(smem + 128 * 512);
@@ -650,6 +664,34 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) t += src[q * 128];
       if (t != 0.f) atomicAdd((tid >> 7) ? &a.lnb_db[tid & 127] : &a.lnb_dw[tid & 127], t);
+    }
+    if (a.lnb_wt) {
+      // DATT = dg1 x W_out: each wave takes 16 rows of the tile (B operand from the 16-bit rows above) against the whole 128 x 128
+      // transposed weight (A operand fragments straight from the pack): 32 MFMAs per wave; (the barrier above ordered the row writes)
+      const int row = wave * 16 + r;
+      bf16x8 xb[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) xb[ks] = *reinterpret_cast<const bf16x8*>(stage + row * 512 + (((ks * 4 + g) ^ (row & 15)) << 4));
+      f32x4 acc[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 wa[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(a.lnb_wt + (size_t)(i * 4 + ks) * 512 + lane * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = DX_MFMA_H16(wa[i], xb[ks], acc[i]);
+      }
+      if (row < len_cols) {
+        dx_h16* const orow = a.lnb_datt + ((size_t)b * a.N + n0 + row) * 128 + g * 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          bf16x4 o4;
+          o4[0] = (dx_h16)acc[i][0]; o4[1] = (dx_h16)acc[i][1]; o4[2] = (dx_h16)acc[i][2]; o4[3] = (dx_h16)acc[i][3];
+          *reinterpret_cast<bf16x4*>(orow + i * 16) = o4;
+        }
+      }
     }
   } else {
     f32x4 old[8];
@@ -732,6 +774,7 @@ static int ff_pair_launch(const void* X, int ldx, const void* Wa, const void* Wb
     a.lnp_w = prologue->lnp_w; a.lnp_b = prologue->lnp_b; a.lnp_film = prologue->lnp_film; a.lnp_ld_film = prologue->lnp_ld_film;
     a.lnp_dg = prologue->lnp_dg; a.lnp_dw = prologue->lnp_dw; a.lnp_db = prologue->lnp_db; a.lnp_dfilm = prologue->lnp_dfilm;
     a.lnp_ld_dfilm = prologue->lnp_ld_dfilm; a.lnp_seed = prologue->lnp_seed; a.lnp_thresh = prologue->lnp_thresh; a.lnp_inv_keep = prologue->lnp_inv_keep;
+    a.lnb_wt = prologue->lnb_wt; a.lnb_datt = prologue->lnb_datt;
   }
 #ifdef DX_FFPAIR_STAMPS
   a.stamps = g_ffpair_stamps;
@@ -798,13 +841,15 @@ int dx_ff_block_bwd(const float* dY2, const float* z2, const float* mean2, const
                     const void* Wa, const void* Wb, const void* aux, int ld_aux, void* H, int ldh, float* Y,
                     int B, int N, int F, const int* lens, int skip_halo,
                     const float* z1, const float* mean1, const float* rstd1, const float* ln1_w, const float* ln1_b, void* DG1, float* dw1, float* db1,
-                    uint64_t seed1, float p1, const uint64_t* seed_offset, void* stream) {
+                    uint64_t seed1, float p1, const void* Wout_bwd, void* DATT, const uint64_t* seed_offset, void* stream) {
   DX_REQUIRE(ln1_w != nullptr && ln2_w != nullptr, "dx_ff_block_bwd: null pointer");
+  DX_REQUIRE((Wout_bwd == nullptr) == (DATT == nullptr) && ((uintptr_t)Wout_bwd % 16) == 0 && ((uintptr_t)DATT % 16) == 0, "dx_ff_block_bwd: Wout_bwd and DATT come together, 16-byte aligned");
   DX_REQUIRE(p2 >= 0.f && p2 < 1.f, "dx_ff_block_bwd: dropout p out of range");
   DX_REQUIRE(!film || (ld_film >= 256 && ld_dfilm >= 256), "dx_ff_block_bwd: ld_film / ld_dfilm too small");
   FFPairArgs pro{};
   pro.lnp_dy = dY2; pro.lnp_z = z2; pro.lnp_mean = mean2; pro.lnp_rstd = rstd2; pro.lnp_w = ln2_w; pro.lnp_b = ln2_b;
   pro.lnp_film = film; pro.lnp_ld_film = ld_film; pro.lnp_dg = (dx_h16*)DG2; pro.lnp_dw = dw2; pro.lnp_db = db2; pro.lnp_dfilm = dfilm;
+  pro.lnb_wt = (const dx_h16*)Wout_bwd; pro.lnb_datt = (dx_h16*)DATT;
   pro.lnp_ld_dfilm = ld_dfilm; pro.lnp_seed = (unsigned long long)seed2; pro.lnp_thresh = (unsigned)lrintf(p2 * 65536.f); pro.lnp_inv_keep = 1.f / (1.f - p2);
   return ff_pair_launch(nullptr, 128, Wa, Wb, nullptr, nullptr, aux, ld_aux, H, ldh, Y, 128, B, N, F, 0, 1, lens, skip_halo, nullptr,
                         nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, (unsigned long long)seed1, p1, (const unsigned long long*)seed_offset,

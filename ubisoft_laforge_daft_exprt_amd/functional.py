@@ -209,43 +209,37 @@ class FFTBlockFn(torch.autograd.Function):
         g = sk.get
         sh = ops.gemm_shadow(prec)
         so = ctx.seed_offset
-        ln1_done = None
-        whole = ctx.fused and ops._FF_LNBWD and ops._FF_BLOCK_BWD and sh and (film is None or film.stride(-1) == 1)
-        if whole:
+        if ctx.fused and ops._FF_BLOCK_BWD and sh and (film is None or film.stride(-1) == 1):
             # LayerNorm2-backward (prologue) -> conv2^T -> ReLU mask -> conv1^T -> LayerNorm1-backward (epilogue): ONE launch
-            (dz1_, dh, dproj_, dff, dfilm, dln2_w, dln2_b, dl1w, dl1b) = ops.ff_block_bwd(
+            # ... -> the out-projection's input gradient (datt) on the same tile
+            fuse_datt = att.dtype == ops._H16[prec] and ops._FF_BLOCK_DATT
+            dz1, dh, dproj, dff, dfilm, dln2_w, dln2_b, dln1_w, dln1_b, datt = ops.ff_block_bwd(
                 dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, packs['c1'], packs['c2'], L, h, z1, mean1, rstd1, ln1_w, ln1_b,
                 seed2=s_ln2, p2=p_conv, seed1=s_ln1, p1=p_attn, seed_offset=so, prec=prec, arena=arena,
-                sinks={'ln2_w': g('ln2_w'), 'ln2_b': g('ln2_b'), 'ln1_w': g('ln1_w'), 'ln1_b': g('ln1_b')})
-            ln1_done = (dz1_, dh, dproj_, dl1w, dl1b)
+                sinks={'ln2_w': g('ln2_w'), 'ln2_b': g('ln2_b'), 'ln1_w': g('ln1_w'), 'ln1_b': g('ln1_b')},
+                out_pack=packs['out'] if fuse_datt else None)
+            dc2_w, dc2_b = ops.conv_wgrad(dff, h, packs['c2'], L, 0, arena=arena, w_sink=g('c2_w'), b_sink=g('c2_b'), prec=prec, defer=True)
         else:
+            datt = None
             r2 = ops.ln_bwd(dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, L, want_da=p_conv > 0, seed_pre=s_ln2, seed_offset=so, prec=prec,
                             p_pre=p_conv, arena=arena, w_sink=g('ln2_w'), b_sink=g('ln2_b'), shadow=sh)
             dz2, da2, dln2_w, dln2_b, dfilm = r2[:5]
             dff = r2[5] if sh else (da2 if da2 is not None else dz2)      # gradient w.r.t. the conv2 output, as the GEMMs read it
-        dc2_w, dc2_b = ops.conv_wgrad(dff, h, packs['c2'], L, 0, arena=arena, w_sink=g('c2_w'), b_sink=g('c2_b'), prec=prec, defer=True)
-        if whole:
-            pass
-        elif ctx.fused and ops._FF_LNBWD and sh and dz2.is_contiguous():
-            # ... and the backward of the first LayerNorm on the output tile while it is in LDS: dz2's buffer comes back holding dz1
-            ln1_done = ops.ff_pair_lnbwd(dff, packs['c1'], packs['c2'], L, h, dz2, z1, mean1, rstd1, ln1_w, ln1_b, seed_pre=s_ln1, p_pre=p_attn,
-                                         seed_offset=so, prec=prec, arena=arena, w_sink=g('ln1_w'), b_sink=g('ln1_b'))
-            dh = ln1_done[1]
-        elif ctx.fused:  # conv2^T -> ReLU mask -> conv1^T in one launch, accumulated into the residual-branch gradient
-            dy1, dh = ops.ff_pair(dff, packs['c1'], packs['c2'], None, None, L, backward=True, aux=h, out=dz2, accumulate=True, prec=prec)
-        else:
-            dh = ops.conv_gemm(dff, packs['c2'], None, transpose=True, relu_aux=h, lens=L, halo=1, out_dtype=h.dtype, prec=prec)
-            dy1 = ops.conv_gemm(dh, packs['c1'], None, transpose=True, out=dz2, accumulate=True, lens=L, halo=0, prec=prec)  # + residual branch
-        dc1_w, dc1_b = ops.conv_wgrad(dh, y1, packs['c1'], L, 1, arena=arena, w_sink=g('c1_w'), b_sink=g('c1_b'), prec=prec, defer=True)
-        if ln1_done is not None:
-            dz1, _, dproj, dln1_w, dln1_b = ln1_done
-        else:
+            # (before the pair below accumulates onto dz2 in place: without a 16-bit shadow and without dropout dff IS dz2)
+            dc2_w, dc2_b = ops.conv_wgrad(dff, h, packs['c2'], L, 0, arena=arena, w_sink=g('c2_w'), b_sink=g('c2_b'), prec=prec, defer=True)
+            if ctx.fused:  # conv2^T -> ReLU mask -> conv1^T in one launch, accumulated into the residual-branch gradient
+                dy1, dh = ops.ff_pair(dff, packs['c1'], packs['c2'], None, None, L, backward=True, aux=h, out=dz2, accumulate=True, prec=prec)
+            else:
+                dh = ops.conv_gemm(dff, packs['c2'], None, transpose=True, relu_aux=h, lens=L, halo=1, out_dtype=h.dtype, prec=prec)
+                dy1 = ops.conv_gemm(dh, packs['c1'], None, transpose=True, out=dz2, accumulate=True, lens=L, halo=0, prec=prec)  # + residual branch
             r1 = ops.ln_bwd(dy1, z1, mean1, rstd1, ln1_w, ln1_b, None, L, want_da=p_attn > 0, seed_pre=s_ln1, seed_offset=so, prec=prec,
                             p_pre=p_attn, arena=arena, w_sink=g('ln1_w'), b_sink=g('ln1_b'), shadow=sh)
             dz1, da1, dln1_w, dln1_b = r1[:4]
             dproj = r1[5] if sh else (da1 if da1 is not None else dz1)
+        dc1_w, dc1_b = ops.conv_wgrad(dh, y1, packs['c1'], L, 1, arena=arena, w_sink=g('c1_w'), b_sink=g('c1_b'), prec=prec, defer=True)
         dout_w, dout_b = ops.conv_wgrad(dproj, att, packs['out'], L, 0, arena=arena, w_sink=g('out_w'), b_sink=g('out_b'), prec=prec, defer=True)
-        datt = ops.conv_gemm(dproj, packs['out'], None, transpose=True, lens=L, halo=0, prec=prec, out_dtype=att.dtype)   # stored like the context
+        if datt is None:
+            datt = ops.conv_gemm(dproj, packs['out'], None, transpose=True, lens=L, halo=0, prec=prec, out_dtype=att.dtype)   # stored like the context
         dqkv = ops.attention_bwd(qkv, att, datt, lse, L, ctx.heads, s_attn, p_attn, out_dtype=qkv.dtype, prec=prec, seed_offset=so)
         din_w, din_b = ops.conv_wgrad(dqkv, x, packs['in'], L, 0, arena=arena, w_sink=g('in_w'), b_sink=g('in_b'), prec=prec, defer=True)
         dx = ops.conv_gemm(dqkv, packs['in'], None, transpose=True, out=dz1, accumulate=True, lens=L, halo=0, prec=prec)  # + residual branch

@@ -350,13 +350,15 @@ def ff_pair_lnbwd(x, pack1: PackedWeight, pack2: PackedWeight, lens, aux, out, z
 
 
 _FF_BLOCK_BWD = os.environ.get('DX_FF_BLOCK_BWD', '1') != '0'
+_FF_BLOCK_DATT = os.environ.get('DX_FF_BLOCK_DATT', '1') != '0'
 
 
 def ff_block_bwd(dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, pack1: PackedWeight, pack2: PackedWeight, lens, aux, z1, mean1, rstd1, ln1_w, ln1_b, *,
-                 seed2=0, p2=0.0, seed1=0, p1=0.0, seed_offset=None, halo=1, prec=None, arena=None, sinks=None):
+                 seed2=0, p2=0.0, seed1=0, p1=0.0, seed_offset=None, halo=1, prec=None, arena=None, sinks=None, out_pack=None):
     """LayerNorm2-backward -> input-gradient pair -> LayerNorm1-backward in one launch (dx_ff_block_bwd).  ``sinks``: dict with optional
-    pre-zeroed ``.grad`` tensors 'ln2_w', 'ln2_b', 'ln1_w', 'ln1_b'.  Returns (dz1, dh, dg1_16bit, dg2_16bit, dfilm or None,
-    dln2_w, dln2_b, dln1_w, dln1_b) -- the four affine gradients are None where a sink took them."""
+    pre-zeroed ``.grad`` tensors 'ln2_w', 'ln2_b', 'ln1_w', 'ln1_b'.  ``out_pack``: the attention out-projection's PackedWeight (128 x 128):
+    the launch then also produces datt = dg1 x W_out.  Returns (dz1, dh, dg1_16bit, dg2_16bit, dfilm or None, dln2_w, dln2_b, dln1_w,
+    dln1_b, datt or None) -- the four affine gradients are None where a sink took them."""
     prec = pack1.rt.precision if prec is None else prec
     B, N, D = dy2.shape
     Fc = pack1.cout
@@ -369,14 +371,20 @@ def ff_block_bwd(dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, pack1: PackedWeight,
     dg2 = torch.empty(B, N, 128, dtype=_H16[prec], device=dev)
     acc = {k: (sinks.get(k) if sinks.get(k) is not None else _zeros(arena, 128, device=dev)) for k in ('ln2_w', 'ln2_b', 'ln1_w', 'ln1_b')}
     dfilm = _zeros(arena, B, 256, device=dev) if film is not None else None
+    datt = wt = None
+    if out_pack is not None:
+        if out_pack.cin != 128 or out_pack.cout != 128 or out_pack.taps != 1:
+            raise ValueError('out_pack must be the (128, 128) out-projection')
+        wt = out_pack.image(prec).bwd
+        datt = torch.empty(B, N, 128, dtype=_H16[prec], device=dev)
     _log(pack1, ('ffpair', B * N, N, 128, Fc, 3))
     _fn('dx_ff_block_bwd', prec)(_p(dy2), _p(z2), _p(mean2), _p(rstd2), _p(ln2_w), _p(ln2_b), _p(film), 0 if film is None else film.stride(0),
                                  _p(dg2), _p(acc['ln2_w']), _p(acc['ln2_b']), _p(dfilm), 256, seed2, float(p2),
                                  _p(i2.bwd), _p(i1.bwd), _p(aux), _rows(aux), _p(dh), _rows(dh), _p(dz1), B, N, Fc, _p(lens), int(halo),
                                  _p(z1), _p(mean1), _p(rstd1), _p(ln1_w), _p(ln1_b), _p(dg1), _p(acc['ln1_w']), _p(acc['ln1_b']),
-                                 seed1, float(p1), _p(seed_offset), _stream())
+                                 seed1, float(p1), _p(wt), _p(datt), _p(seed_offset), _stream())
     ret = lambda k: None if sinks.get(k) is not None else acc[k]
-    return dz1, dh, dg1, dg2, dfilm, ret('ln2_w'), ret('ln2_b'), ret('ln1_w'), ret('ln1_b')
+    return dz1, dh, dg1, dg2, dfilm, ret('ln2_w'), ret('ln2_b'), ret('ln1_w'), ret('ln1_b'), datt
 
 
 class ZeroArena:
