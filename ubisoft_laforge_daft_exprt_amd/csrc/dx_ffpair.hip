@@ -26,6 +26,13 @@
 //   The 130-row activation tile (126 + 2 halo rows each side) is staged once.
 // Token tile = 126, not 128: the hidden rows a tile needs are then exactly 128 = 8 MFMA column tiles (a 128-token tile would
 // need 130 rows = 9 column tiles, 12 % wasted matrix work in the first conv).
+//
+// Row passes folded into the two ends of the kernel (a 126 x 128 tile owns whole rows of the 128-wide streams):
+//   forward epilogue (dx_ff_pair_ln)      dropout + residual + the block's SECOND LayerNorm + FiLM + mask on the output tile (model.py:225-233)
+//   backward prologue (dx_ff_block_bwd)   the backward of that LayerNorm COMPUTES the activation tile (rows + halo) instead of loading it
+//   backward epilogue (dx_ff_pair_lnbwd,  the backward of the block's FIRST LayerNorm on the output tile, then - dx_ff_block_bwd - the
+//                      dx_ff_block_bwd)   attention out-projection's input-gradient GEMM on the resulting 16-bit rows
+// Each removes a launch and an HBM round trip of a 512 B/token tensor; they use registers only after / before the slice loop.
 #include "dx_common.h"
 #include <algorithm>
 
