@@ -328,7 +328,6 @@ def ff_pair_ln(x, pack1: PackedWeight, pack2: PackedWeight, bias1, bias2, lens, 
     return z, h, y, mean, rstd
 
 
-_FF_LNBWD = os.environ.get('DX_FF_LNBWD', '1') != '0'
 
 
 def ff_pair_lnbwd(x, pack1: PackedWeight, pack2: PackedWeight, lens, aux, out, z, mean, rstd, ln_w, ln_b, *, seed_pre=0, p_pre=0.0, seed_offset=None,
