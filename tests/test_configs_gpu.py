@@ -172,6 +172,46 @@ def test_c2_bf16_forward_loss_gradients_vs_oracle(pkg, c2, precision):
         assert cos >= BF16_GRAD_COS_SMALL, (k, rel, cos)
 
 
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+def test_c2_trainer_gradient_path_equals_plain_autograd(pkg, c2, precision):
+    """The gradients the TRAINER computes on the C2 batch - kernels accumulating straight into the all-reduce buckets (sink), the FFT
+    blocks' weight gradients queued and launched eight layers at a time, the step arena, loss scaling in fp16 - against plain autograd
+    (.grad tensors, one launch per weight gradient) of the same model, same mode, dropout off: same kernels, other summation orders."""
+    from ubisoft_laforge_daft_exprt_amd.trainer import Trainer
+    hp, batch, _ = c2
+    hp = hp.without_dropout() if hasattr(hp, 'without_dropout') else hp
+    plain = _hip_step(pkg, batch, hp, precision)['grads']
+    pkg.set_precision(precision)
+    try:
+        model = pkg.DaftExprt(hp).to(DEV)
+        model.load_state_dict(helpers.golden_state_dict(), strict=True)
+        crit = pkg.DaftExprtLoss(DEV, hp)
+        crit.load_pitch_predictor(helpers.golden_pitch_predictor_state_dict())
+    finally:
+        pkg.set_precision('f32')
+    t = Trainer(model, crit, hp, use_graphs=False)
+    assert model.runtime.sink and model.runtime.defer_wgrad
+    t.iteration = ITERATION
+    dev_batch = tuple(x.to(DEV) if torch.is_tensor(x) else x for x in batch)
+    parsed, _ = t._parse([dev_batch])
+    _, _, phase_b = t._phases(parsed, ITERATION, t.reducer.launch_group)      # the eager form of train_step, without the optimiser
+    phase_b()
+    t.reducer.finish()
+    torch.cuda.synchronize()
+    assert not model.runtime.wgrad_queue
+    scale = t.loss_scale
+    worst = ('', 0.0)
+    for k, prm in model.named_parameters():
+        g = prm.grad.detach().cpu().double() / scale
+        r = plain[k].double()
+        rel = float((g - r).abs().max() / r.abs().max().clamp_min(1e-30))
+        if rel > worst[1]:
+            worst = (k, rel)
+    print(f'C2 {precision}: trainer gradient path vs plain autograd, worst relative difference {worst[1]:.2e} at {worst[0]}')
+    assert worst[1] < 2e-3, worst
+    t.reducer.remove()
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # C4: B = 256 inference
 # ----------------------------------------------------------------------------------------------------------------------
