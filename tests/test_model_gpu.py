@@ -1,6 +1,8 @@
 """End-to-end parity of the HIP path (through the C ABI) against the golden fixtures written by the reference, and against
 the CPU oracle on larger seeded batches.  fp32 operands (``set_precision('f32')``); tolerance target from BASELINE.json:
 mean |mel - mel_ref| <= 1e-4 over valid frames (we assert 2e-5), integer paths bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -323,6 +325,62 @@ def test_long_form_bf16_mode_runs_and_tracks_fp32(dx, precision, tol):
     l1 = valid_mel_l1(got.cpu().numpy(), ref.cpu().numpy(), batch[9])
     print(precision, '-vs-f32 valid mel L1 (long form)', l1)
     assert l1 < tol
+
+
+C5_MEL_L1 = {'bf16': 2e-2, 'fp16': 5e-3}       # stated tolerances of the long-form reduced-precision test below
+C5_GRAD_COS = {'bf16': 0.99, 'fp16': 0.995}
+C5_GRAD_REL = {'bf16': 0.15, 'fp16': 0.10}
+
+
+def test_long_form_reduced_precision_forward_backward_vs_oracle(dx):
+    """BASELINE.json config 5 (long-form stress, fp16 named): ONE utterance of 500 symbols / 4500 frames through forward, loss and
+    backward in the fp16 and bf16 operand modes against the CPU oracle (one oracle step, ~1 minute): valid-frame mel L1, the seven loss
+    terms, per-parameter gradient cosine / relative error (tensors of >= 64 elements), with the tolerances stated above.  At this length
+    the frame axis has 36 key tiles per attention row and 36 token tiles per utterance: every tiled kernel runs many tiles of ONE row."""
+    from oracle import daft_exprt_oracle as oracle
+    hp = helpers.golden_hparams()
+    full = _c5_batch(hp.n_speakers)
+    batch = tuple(t[:1] if torch.is_tensor(t) else t[:1] for t in full)
+    sd = helpers.golden_state_dict()
+    for v in sd.values():
+        v.requires_grad_(True)
+    cpu_inputs = tuple(batch[i] for i in range(11)) + (batch[13],)
+    cpu_targets = (batch[1], batch[3], batch[4], batch[8], batch[9], batch[10], batch[6], batch[7])
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    ref_out = oracle.forward(sd, cpu_inputs, hp, training=True)
+    ref_total, ref_terms = oracle.loss(ref_out, cpu_targets, 3000, hp, helpers.golden_pitch_predictor_state_dict())
+    ref_total.backward()
+    ref_mel = ref_out[3][0].detach().numpy()
+    for precision in ('fp16', 'bf16'):
+        model = build_model(dx, hp).train()
+        model.set_precision(precision)
+        crit = build_loss(dx, hp)
+        crit.set_precision(precision)
+        inputs, targets = model.parse_batch(DEV, batch)
+        out = model(inputs)
+        total, terms = crit(out, targets + (inputs[6], inputs[7]), 3000)
+        scale = 4096.0 if precision == 'fp16' else 1.0
+        (total * scale).backward()
+        l1 = valid_mel_l1(out[3][0].detach().cpu().numpy(), ref_mel, batch[9])
+        worst_cos, worst_rel = ('', 1.0), ('', 0.0)
+        for k, prm in model.named_parameters():
+            if prm.numel() < 64:
+                continue
+            g = (prm.grad.detach().cpu().double() / scale).flatten()
+            r = sd[k].grad.double().flatten()
+            cos = float((g @ r) / (g.norm() * r.norm()).clamp_min(1e-30))
+            rel = float((g - r).abs().max() / r.abs().max().clamp_min(1e-30))
+            if cos < worst_cos[1]:
+                worst_cos = (k, cos)
+            if rel > worst_rel[1]:
+                worst_rel = (k, rel)
+        term_rel = max(abs(float(terms[k]) - float(ref_terms[k])) / max(abs(float(ref_terms[k])), 1e-12) for k in ref_terms)
+        print(f'long form {precision}: mel L1 {l1:.2e}, loss terms rel <= {term_rel:.2e}, worst gradient cosine {worst_cos[1]:.5f} ({worst_cos[0]}), '
+              f'worst relative {worst_rel[1]:.2e} ({worst_rel[0]})')
+        assert l1 < C5_MEL_L1[precision]
+        assert term_rel < 2e-2
+        assert worst_cos[1] > C5_GRAD_COS[precision], worst_cos
+        assert worst_rel[1] < C5_GRAD_REL[precision], worst_rel
 
 
 def test_graph_captured_inference_matches_eager_and_golden(dx):
