@@ -188,7 +188,7 @@ int dx_mean_pool(const float* x, const int* lens, float* out, int B, int N, int 
 int dx_mean_pool_bwd(const float* dout, const int* lens, float* dx, int B, int N, int C, void* stream);
 int dx_transpose(const float* in, float* out, int B, int R, int Cc, void* stream);
 int dx_relu_bwd(const float* dy, const float* y, float* out, long n, void* stream);
-int dx_channel_affine(const float* x, const float* scale, const float* shift, float* out, long rows, int C, void* stream); /* layers/pitch_predictor.py:49-62 (BatchNorm1d, eval) */
+int dx_channel_affine(const void* x, const float* scale, const float* shift, void* out, long rows, int C, int io_bf16, void* stream); /* layers/pitch_predictor.py:49-62 (BatchNorm1d, eval); io_bf16: x / out stored in the mode's 16-bit type */
 int dx_l2_normalize(const float* x, float* y, int rows, int C, void* stream);            /* model.py:904 */
 int dx_cross_entropy(const float* logits, const long* target, float* loss, float* dlogits, int B, int S, void* stream); /* loss.py:85 */
 

@@ -458,6 +458,22 @@ def test_ff_block_backward_equals_three_launches(ops, precision, p_drop, use_fil
         ops.set_precision('f32')
 
 
+@pytest.mark.parametrize('precision', ['f32', 'bf16', 'fp16'])
+def test_channel_affine_vs_torch(ops, precision):
+    """dx_channel_affine (eval-mode BatchNorm of the frozen pitch predictor, layers/pitch_predictor.py:49-62) in fp32 and in the 16-bit
+    storage of the two reduced operand modes: the result is the fp32 affine of the stored value, rounded once."""
+    ops.set_precision(precision)
+    try:
+        x = randn(3, 217, 256, seed=4).to(ops.hidden_dtype())
+        sc, sh = randn(256, seed=5), randn(256, seed=6)
+        y = ops.channel_affine(x, sc, sh)
+        ref = x.float() * sc + sh
+        ulp = {'f32': 2.0 ** -23, 'bf16': 2.0 ** -8, 'fp16': 2.0 ** -11}[precision]     # one rounding of the stored result (+ fma contraction)
+        assert y.dtype == x.dtype and bool(((y.float() - ref).abs() <= 1.01 * ulp * ref.abs() + 1e-6).all())
+    finally:
+        ops.set_precision('f32')
+
+
 @pytest.mark.parametrize('with_pm', [True, False])
 def test_film_affine_forward_backward_vs_torch(ops, with_pm):
     """FilmAffineFn (StyleAdapter tail, model.py:779-800) against the element-wise torch formulation, incl. blocks that receive no gradient."""

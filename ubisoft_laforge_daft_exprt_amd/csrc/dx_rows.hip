@@ -662,16 +662,26 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
 
-// out[row][c] = x[row][c] * scale[c] + shift[c]     (eval-mode BatchNorm of the frozen pitch predictor)
-__global__ __launch_bounds__(256) void channel_affine_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                             float* __restrict__ out, long rows, int C) {
-  const long total4 = rows * C / 4;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
-    const int c = (int)((i * 4) % C);
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
-    const float4 sc = *reinterpret_cast<const float4*>(scale + c);
-    const float4 sh = *reinterpret_cast<const float4*>(shift + c);
-    reinterpret_cast<float4*>(out)[i] = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+// out[row][c] = x[row][c] * scale[c] + shift[c]     (eval-mode BatchNorm of the frozen pitch predictor); IO = float or the 16-bit type
+template <typename IO>
+__global__ __launch_bounds__(256) void channel_affine_kernel(const IO* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             IO* __restrict__ out, long rows, int C) {
+  constexpr int V = sizeof(IO) == 4 ? 4 : 8;          // elements per 16-byte access
+  const long totalv = rows * C / V;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < totalv; i += (long)gridDim.x * 256) {
+    const int c = (int)((i * V) % C);
+    if constexpr (sizeof(IO) == 4) {
+      const float4 v = reinterpret_cast<const float4*>(x)[i];
+      const float4 sc = *reinterpret_cast<const float4*>(scale + c);
+      const float4 sh = *reinterpret_cast<const float4*>(shift + c);
+      reinterpret_cast<float4*>(out)[i] = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+    } else {
+      const bf16x8 v = reinterpret_cast<const bf16x8*>(x)[i];
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (dx_h16)((float)v[e] * scale[c + e] + shift[c + e]);
+      reinterpret_cast<bf16x8*>(out)[i] = o;
+    }
   }
 }
 
@@ -937,10 +947,12 @@ int dx_relu_bwd(const float* dy, const float* y, float* out, long n, void* strea
   return DX_OK;
 }
 
-int dx_channel_affine(const float* x, const float* scale, const float* shift, float* out, long rows, int C, void* stream) {
-  DX_REQUIRE(x && scale && shift && out && rows > 0 && C > 0 && (C % 4) == 0, "dx_channel_affine: bad arguments");
-  const long total4 = rows * C / 4;
-  hipLaunchKernelGGL(channel_affine_kernel, dim3((int)std::min<long>((total4 + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, out, rows, C);
+int dx_channel_affine(const void* x, const float* scale, const float* shift, void* out, long rows, int C, int io_bf16, void* stream) {
+  DX_REQUIRE(x && scale && shift && out && rows > 0 && C > 0 && (C % 8) == 0, "dx_channel_affine: bad arguments (C must be a multiple of 8)");
+  const long totalv = rows * C / (io_bf16 ? 8 : 4);
+  const dim3 grid((int)std::min<long>((totalv + 255) / 256, 8192));
+  if (io_bf16) hipLaunchKernelGGL(channel_affine_kernel<dx_h16>, grid, dim3(256), 0, (hipStream_t)stream, (const dx_h16*)x, scale, shift, (dx_h16*)out, rows, C);
+  else hipLaunchKernelGGL(channel_affine_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, scale, shift, (float*)out, rows, C);
   DX_LAUNCH_CHECK("dx_channel_affine");
   return DX_OK;
 }

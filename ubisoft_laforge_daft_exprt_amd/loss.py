@@ -7,11 +7,16 @@ handed to autograd by ``_LossFn``.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
 from . import ops
 from .functional import Lengths
+
+
+_PITCH_16BIT = os.environ.get('DX_PITCH_16BIT', '1') != '0'
 
 
 def pitch_predictor_shapes(n_mel_channels=80, hidden_dim=256, kernel_size=3):
@@ -94,10 +99,11 @@ class _LossFn(torch.autograd.Function):
             prec = pitch_layers[0]['pack'].rt.precision                          # one value for the whole chain
             acts = []
             depth = len(pitch_layers) - 1                                       # stacked k=3 convs: halos 3, 2, 1, 0
-            for i, layer in enumerate(pitch_layers[:-1]):
-                r = ops.conv_gemm(x, layer['pack'], layer['b'], relu=True, lens=lens.i32, halo=depth - i, prec=prec)
+            hd = ops.hidden_dtype(prec) if _PITCH_16BIT else torch.float32     # 16-bit modes: the 256-wide activations of the frozen predictor
+            for i, layer in enumerate(pitch_layers[:-1]):                      # (only ever GEMM operands / ReLU masks) are stored in 16 bits
+                r = ops.conv_gemm(x, layer['pack'], layer['b'], relu=True, lens=lens.i32, halo=depth - i, prec=prec, out_dtype=hd)
                 acts.append(r)
-                x = ops.channel_affine(r, layer['scale'], layer['shift'])
+                x = ops.channel_affine(r, layer['scale'], layer['shift'], prec=prec)
             last = pitch_layers[-1]
             pp = ops.conv_gemm(x, last['pack'], last['b'], lens=lens.i32, halo=0, prec=prec)[:, :, 0].contiguous()  # (B, T)
             frames_pitch = frames_pitch.contiguous()
@@ -109,7 +115,7 @@ class _LossFn(torch.autograd.Function):
             for k in range(len(pitch_layers) - 1, 0, -1):
                 prev = pitch_layers[k - 1]
                 g = ops.conv_gemm(g, pitch_layers[k]['pack'], None, transpose=True, post_scale=prev['scale'], post_shift=prev['zeros'],
-                                  relu_aux=acts[k - 1], lens=lens.i32, halo=depth - k + 1, prec=prec)
+                                  relu_aux=acts[k - 1], lens=lens.i32, halo=depth - k + 1, prec=prec, out_dtype=hd)
             d = ops.conv_gemm(g, pitch_layers[0]['pack'], None, transpose=True, lens=lens.i32, halo=0, prec=prec)
             dmel = dmel + ops.transpose(d)
         # the seven terms, the total and the two small gradients: one launch (was ~30 one-element ATen launches)

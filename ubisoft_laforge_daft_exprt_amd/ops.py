@@ -791,7 +791,8 @@ def relu_bwd(dy, y):
     return out
 
 
-def channel_affine(x, scale, shift):
+def channel_affine(x, scale, shift, prec=None):
     out = torch.empty_like(x)
-    lib().dx_channel_affine(_p(x), _p(scale), _p(shift), _p(out), x.numel() // x.shape[-1], x.shape[-1], _stream())
+    fn = _fn('dx_channel_affine', prec or DEFAULT.precision) if _is_bf16(x) else lib().dx_channel_affine
+    fn(_p(x), _p(scale), _p(shift), _p(out), x.numel() // x.shape[-1], x.shape[-1], _is_bf16(x), _stream())
     return out

@@ -151,7 +151,7 @@ def price(name, a, geom: Geometry):
     if name == 'dx_mean_pool_bwd':
         return 'mean_pool_bwd', 'hbm', None, geom.rows(a['B'], a['N']) * a['C'] * 4
     if name == 'dx_channel_affine':
-        return 'channel_affine', 'hbm', None, 2 * a['rows'] * a['C'] * 4
+        return 'channel_affine', 'hbm', None, 2 * a['rows'] * a['C'] * (2 if a.get('io_bf16') else 4)
     if name == 'dx_relu_bwd':
         return 'relu_bwd', 'hbm', None, 3 * a['n'] * 4
     if name == 'dx_colsum':
