@@ -60,13 +60,15 @@ class GradientReducer:
             self.buckets.append(cur)
             self.bucket_group.append(cur_g)
         self.flat, self.bucket_of = [], {}
-        # ONE allocation for all buckets (each a 16-byte aligned slice): zeroing, the gradient norm and the fused Adam step are then one
-        # launch each over the whole range instead of one per bucket; the gaps between buckets stay zero
+        # ONE allocation for all buckets: zeroing, the gradient norm and the fused Adam step are then one launch each over the whole range
+        # instead of one per bucket; the gaps between buckets stay zero.  Every bucket starts on a 4 KB boundary: a bucket under exchange
+        # (the collective's loads / stores, on its own queue) then shares no cache line or page with a bucket whose gradients are still
+        # receiving the backward kernels' memory-side float atomics.
         sizes = [sum(p.numel() for p in bucket) for bucket in self.buckets]
         self.bucket_offset, total = [], 0
         for n in sizes:
             self.bucket_offset.append(total)
-            total += (n + 3) // 4 * 4
+            total += (n + 1023) // 1024 * 1024
         self.flat_all = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
         for bi, bucket in enumerate(self.buckets):
             n = sizes[bi]
