@@ -212,6 +212,53 @@ def test_c2_trainer_gradient_path_equals_plain_autograd(pkg, c2, precision):
     t.reducer.remove()
 
 
+def test_c2_phase_b_gradients_with_bucket_traffic_on_another_queue(pkg, c2):
+    """What an N > 1 step does on the device, on one GPU: while phase B (accent-encoder backward, its kernels adding into group 1's
+    buckets with memory-side float atomics) runs on the compute stream, another queue reads and rewrites group 0's buckets in place, as
+    the all-reduce does.  Every gradient must equal the serial step's (summation order only), group 0's included."""
+    from ubisoft_laforge_daft_exprt_amd.trainer import Trainer
+    hp, batch, _ = c2
+    hp = hp.without_dropout() if hasattr(hp, 'without_dropout') else hp
+    pkg.set_precision('bf16')
+    try:
+        model = pkg.DaftExprt(hp).to(DEV)
+        model.load_state_dict(helpers.golden_state_dict(), strict=True)
+        crit = pkg.DaftExprtLoss(DEV, hp)
+        crit.load_pitch_predictor(helpers.golden_pitch_predictor_state_dict())
+    finally:
+        pkg.set_precision('f32')
+    t = Trainer(model, crit, hp, use_graphs=False)
+    t.iteration = ITERATION
+    red = t.reducer
+    assert sorted(set(red.bucket_group)) == [0, 1] and all(o % 1024 == 0 for o in red.bucket_offset)
+    dev_batch = tuple(x.to(DEV) if torch.is_tensor(x) else x for x in batch)
+    parsed, _ = t._parse([dev_batch])
+    side = torch.cuda.Stream()
+
+    def step(traffic):
+        _, _, phase_b = t._phases(parsed, ITERATION, red.launch_group)
+        if traffic:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(12):                               # ~1 ms of in-place traffic over 40 MB, the length of phase B
+                    for bi, flat in enumerate(red.flat):
+                        if red.bucket_group[bi] == 0:
+                            flat.mul_(1.0)
+        phase_b()
+        torch.cuda.current_stream().wait_stream(side)
+        red.finish()
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    serial = step(False)
+    for _ in range(3):
+        got = step(True)
+        worst = max(((float((got[k] - serial[k]).abs().max() / serial[k].abs().max().clamp_min(1e-30)), k) for k in serial))
+        assert worst[0] < 1e-4, worst
+    print(f'C2 bf16: phase B beside bucket traffic on another queue vs serial, worst relative difference {worst[0]:.2e} at {worst[1]}')
+    red.remove()
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # C4: B = 256 inference
 # ----------------------------------------------------------------------------------------------------------------------
