@@ -74,6 +74,7 @@ class LinearFn(torch.autograd.Function):
         y = ops.conv_gemm(x2, pack, bias, relu=relu, lens=lens, mask_rows=lens is not None, prec=ctx.prec)
         ctx.save_for_backward(x2, y if relu else None)
         ctx.pack, ctx.relu, ctx.grad_scale, ctx.lens, ctx.need_dx, ctx.xshape = pack, relu, grad_scale, lens, need_dx, x.shape
+        ctx.params, ctx.sink = (weight, bias), bool(pack.rt.sink)
         return y.view(*x.shape[:-1], y.shape[-1])
 
     @staticmethod
@@ -84,7 +85,9 @@ class LinearFn(torch.autograd.Function):
             dy = ops.mask_rows(dy, ctx.lens)
         if ctx.relu:
             dy = ops.relu_bwd(dy, y)
-        dw, db = ops.conv_wgrad(dy, x2, ctx.pack, prec=ctx.prec)
+        # gradient sink: the weight-gradient launch adds straight into the bucket views (no zero fill, no AccumulateGrad add per parameter)
+        dw, db = ops.conv_wgrad(dy, x2, ctx.pack, arena=ctx.pack.rt.arena, w_sink=_sink(ctx.params[0], ctx.sink), b_sink=_sink(ctx.params[1], ctx.sink),
+                                prec=ctx.prec)
         dx = None
         if ctx.need_dx:
             dx = ops.conv_gemm(dy, ctx.pack, None, transpose=True, out_scale=ctx.grad_scale, prec=ctx.prec).view(ctx.xshape)
@@ -366,13 +369,14 @@ class EmbedPosFn(torch.autograd.Function):
         symbols = symbols.contiguous()
         ctx.save_for_backward(symbols)
         ctx.lens, ctx.rows, ctx.rt = lens, emb.shape[0], rt
+        ctx.emb, ctx.sink = emb, bool(rt is not None and rt.sink)
         return ops.add_pos(None, symbols, emb, pe, lens.i32)
 
     @staticmethod
     def backward(ctx, dout):
         (symbols,) = ctx.saved_tensors
         arena = None if ctx.rt is None else ctx.rt.arena
-        return None, ops.embedding_bwd(dout.contiguous(), symbols, ctx.lens.i32, ctx.rows, arena=arena), None, None, None
+        return None, ops.embedding_bwd(dout.contiguous(), symbols, ctx.lens.i32, ctx.rows, arena=arena, sink=_sink(ctx.emb, ctx.sink)), None, None, None
 
 
 class AddPosFn(torch.autograd.Function):
@@ -432,12 +436,14 @@ class MelProjectionFn(torch.autograd.Function):
         mel_cl = ops.conv_gemm(x, pack, bias, lens=lens.i32, mask_rows=True, halo=0, prec=ctx.prec)
         ctx.save_for_backward(x)
         ctx.pack, ctx.lens = pack, lens
+        ctx.params, ctx.sink = (weight, bias), bool(pack.rt.sink)
         return ops.transpose(mel_cl)
 
     @staticmethod
     def backward(ctx, dmel):
         (x,) = ctx.saved_tensors
         d_cl = ops.mask_rows(ops.transpose(dmel.contiguous()), ctx.lens.i32)
-        dw, db = ops.conv_wgrad(d_cl, x, ctx.pack, ctx.lens.i32, 0, prec=ctx.prec)
+        dw, db = ops.conv_wgrad(d_cl, x, ctx.pack, ctx.lens.i32, 0, arena=ctx.pack.rt.arena, w_sink=_sink(ctx.params[0], ctx.sink),
+                                b_sink=_sink(ctx.params[1], ctx.sink), prec=ctx.prec)
         dx = ops.conv_gemm(d_cl, ctx.pack, None, transpose=True, lens=ctx.lens.i32, halo=0, prec=ctx.prec)
         return dx, dw, db, None, None

@@ -617,11 +617,12 @@ def mask_rows(x, lens):
     return out
 
 
-def embedding_bwd(dout, sym, lens, n_rows, arena=None):
+def embedding_bwd(dout, sym, lens, n_rows, arena=None, sink=None):
+    """``sink``: the pre-zeroed ``.grad`` of the table to add into (the return value is then None)."""
     B, N, D = dout.shape
-    demb = _zeros(arena, n_rows, D, device=dout.device)
+    demb = sink if sink is not None else _zeros(arena, n_rows, D, device=dout.device)
     lib().dx_embedding_bwd(_p(dout), _p(sym), _p(lens), _p(demb), B, N, D, _stream())
-    return demb
+    return None if sink is not None else demb
 
 
 def accent_sum(prenet, energy, pitch, we, be, wp, bp, pe, lens):
