@@ -105,6 +105,14 @@ int dx_ff_pair_ln(const void* X, int ldx, const void* Wa, const void* Wb, const 
                   int B, int N, int F, const int* lens, int skip_halo, const int* rows_exist,
                   const float* res, const float* ln_w, const float* ln_b, const float* film, int ld_film, float* Yln, float* mean, float* rstd,
                   uint64_t seed_pre, float p_pre, const uint64_t* seed_offset, void* stream);
+/* dx_ff_pair_ln followed, on the same tile, by the NEXT FFT block's attention in-projection (model.py:163-171, F.multi_head_attention_forward's
+ * linear(x, in_proj_weight, in_proj_bias)): QKV (16-bit [B][N][384]) = Yln x Wq^T + bias_q, what dx_conv_gemm(Yln, Wq, bias_q, taps = 1,
+ * lens, skip_halo = 0, y 16-bit) writes (rows >= lens[b] of a live tile = the bias; tiles beyond the halo = 0).  Wq: the forward pack of
+ * the (384, 128) weight in the mode's 16-bit type. */
+int dx_ff_pair_ln_qkv(const void* X, int ldx, const void* Wa, const void* Wb, const float* bias_a, const float* bias_b, void* H, int ldh, float* Z,
+                      int B, int N, int F, const int* lens, int skip_halo, const int* rows_exist,
+                      const float* res, const float* ln_w, const float* ln_b, const float* film, int ld_film, float* Yln, float* mean, float* rstd,
+                      uint64_t seed_pre, float p_pre, const uint64_t* seed_offset, const void* Wq, const float* bias_q, void* QKV, void* stream);
 /* dx_ff_pair (input-gradient pair, accumulate = 1) with the BACKWARD of the block's first LayerNorm folded into its epilogue: Y holds the
  * residual-branch gradient on entry and dz1 = LayerNorm-backward(Y + pair result) on return; DG (16-bit [B][N][128]) = dropout(dz1), the
  * operand of the out-projection's backward GEMMs; dw / db (caller-initialised [128]) accumulate the affine gradients.  z / mean / rstd /

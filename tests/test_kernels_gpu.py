@@ -533,6 +533,47 @@ def test_ff_pair_layernorm_epilogue_equals_two_launches(ops, precision, p_drop):
 
 
 @pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+def test_ff_pair_epilogue_produces_next_blocks_qkv(ops, precision):
+    """dx_ff_pair_ln_qkv == dx_ff_pair_ln followed by the next block's in-projection launch (dx_conv_gemm 128 -> 384, halo 0) on its y:
+    everything dx_ff_pair_ln returns is unchanged bit for bit; qkv agrees to the rounding of its 16-bit storage (other fp32 summation
+    order), equals the bias on padded rows of live tiles and zero in tiles beyond the halo."""
+    ops.set_precision(precision)
+    try:
+        h16 = ops.hidden_dtype()
+        B, N, Fc = 5, 300, 1024
+        lens_l = [300, 252, 126, 127, 40]
+        lens = lens_tensor(lens_l)
+        valid = (torch.arange(N, device=DEV)[None, :] < lens[:, None])
+        x = (randn(B, N, 128, seed=1) * valid[:, :, None]).to(h16)
+        w1, b1 = randn(Fc, 128, 3, seed=2, scale=1 / math.sqrt(384)), randn(Fc, seed=3, scale=0.1)
+        w2, b2 = randn(128, Fc, 3, seed=4, scale=1 / math.sqrt(3 * Fc)), randn(128, seed=5, scale=0.1)
+        res = randn(B, N, 128, seed=6)
+        lw, lb = 1 + 0.1 * randn(128, seed=7), randn(128, seed=8, scale=0.1)
+        wq, bq = randn(384, 128, seed=10, scale=1 / math.sqrt(128)), randn(384, seed=11, scale=0.1)
+        p1, p2, pq = ops.PackedWeight(w1), ops.PackedWeight(w2), ops.PackedWeight(wq)
+        assert ops.next_qkv_applies(pq, precision)
+        for film in (None, randn(B, 256, seed=9)):
+            z0, h0, y0, m0, r0 = ops.ff_pair_ln(x, p1, p2, b1, b2, lens, res, lw, lb, film, seed_pre=91, p_pre=0.1)
+            q0 = ops.conv_gemm(y0, pq, bq, lens=lens, halo=0, out_dtype=h16)
+            z1, h1, y1, m1, r1, q1 = ops.ff_pair_ln(x, p1, p2, b1, b2, lens, res, lw, lb, film, seed_pre=91, p_pre=0.1, next_in=(pq, bq))
+            assert torch.equal(h0, h1) and torch.equal(y0, y1)
+            for a, b in ((z0, z1), (m0, m1), (r0, r1)):              # (tiles beyond the halo leave these three unwritten)
+                assert torch.equal(a[valid], b[valid])
+            assert q1.dtype == h16 and q1.shape == (B, N, 384)
+            ulp = 2.0 ** -7 if precision == 'bf16' else 2.0 ** -10
+            diff = (q1.float() - q0.float()).abs()[valid]              # (padded rows: the two launches tile the axis differently, see below)
+            assert float((diff / q0.float()[valid].abs().clamp_min(0.25)).max()) <= 2 * ulp   # at most a rounding step of the 16-bit result
+            assert float((diff > 0).float().mean()) < 0.02                                        # and only where the fp32 sums straddle one
+            for b, n in enumerate(lens_l):
+                live_end = min(N, -(-(n + 1) // 126) * 126)                                      # the 126-token tiles that start before len + halo (1)
+                if n < live_end:
+                    assert torch.equal(q1[b, n:live_end].float(), bq.to(h16).float().expand(live_end - n, 384))
+                assert float(q1[b, live_end:].float().abs().max() if live_end < N else 0.0) == 0.0
+    finally:
+        ops.set_precision('f32')
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
 @pytest.mark.parametrize('p_drop', [0.0, 0.2])
 def test_fused_out_projection_layernorm_equals_two_launches(ops, precision, p_drop):
     """dx_proj_ln_fwd == dx_conv_gemm (128 -> 128) followed by dx_ln_fwd, same seeds: z / mean / rstd / y / 16-bit copy, padded rows,

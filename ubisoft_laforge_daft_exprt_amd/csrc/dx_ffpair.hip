@@ -58,6 +58,9 @@ struct FFPairArgs {
   const float* ln_res; const float* ln_w; const float* ln_b; const float* film; int ld_film;
   float* ln_y; float* ln_mean; float* ln_rstd;
   unsigned long long seed_pre; unsigned thresh_pre; float inv_keep_pre; const unsigned long long* seed_offset;
+  // ... optionally followed by the NEXT block's attention in-projection on the same tile (q_w != null): q_out = ln_y x W_in^T + q_bias,
+  // 16-bit [B][N][384] (q_w: the forward pack of the (384, 128) in-projection weight) -- what dx_conv_gemm(taps = 1, halo 0) writes from ln_y
+  const dx_h16* q_w; const float* q_bias; dx_h16* q_out;
   // optional LayerNorm-BACKWARD epilogue of the input-gradient pair (lnb_w != null): the pair's result + the residual gradient already in Y
   // is d(loss)/d(y1) of the block's FIRST LayerNorm; the epilogue turns the tile into dz1 (written to Y), its dropped-out 16-bit copy for the
   // GEMMs (lnb_dg) and the affine gradients (lnb_dw / lnb_db, atomics) -- dx_ln_bwd with C = 128, no FiLM, halo 0, done while the tile is in LDS
@@ -218,6 +221,11 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
         const int row = u >> 5, q = u & 31;
         *reinterpret_cast<f32x4*>(a.Y + ((size_t)b * a.N + n0 + row) * a.ldy + q * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
         if (a.ln_w) *reinterpret_cast<f32x4*>(a.ln_y + ((size_t)b * a.N + n0 + row) * 128 + q * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    if (a.q_w)
+      for (int u = tid; u < rows * 48; u += 512) {        // 384 16-bit values per row
+        const int row = u / 48, q = u - row * 48;
+        *reinterpret_cast<f32x4*>(a.q_out + ((size_t)b * a.N + n0 + row) * 384 + q * 8) = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     return;
   }
@@ -565,6 +573,13 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
     }
     const int len_b = a.lens ? a.lens[b] : a.N;
     const unsigned long long seed = a.seed_pre + (a.seed_offset ? *a.seed_offset : 0ull);
+    bf16x8 qa[3][4];                                    // next block's in-projection (below): this wave's weight fragments, in flight during the row loop
+    if (a.q_w) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qa[i][ks] = *reinterpret_cast<const bf16x8*>(a.q_w + (size_t)((wave * 3 + i) * 4 + ks) * 512 + lane * 8);
+    }
     f32x4 resv[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {                       // the residual rows of all eight passes are requested first
@@ -601,6 +616,45 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
       if (a.film) y = fg * y + fb;
       if (!valid) y = f32x4{0.f, 0.f, 0.f, 0.f};
       if (inb) *reinterpret_cast<f32x4*>(a.ln_y + grow * 128 + s * 4) = y;
+      if (a.q_w) {
+        // the same row as 16 bits, in place over the fp32 row it came from (this half wave has read all of it), for the GEMM below:
+        // 16 slots of 8 channels, XOR-swizzled by the row; rows the tile does not own are zero operands
+        bf16x4 h4;
+        h4[0] = (dx_h16)y[0]; h4[1] = (dx_h16)y[1]; h4[2] = (dx_h16)y[2]; h4[3] = (dx_h16)y[3];
+        *reinterpret_cast<bf16x4*>(stage + row * 512 + (((s >> 1) ^ (row & 15)) << 4) + ((s & 1) << 3)) = h4;
+      }
+    }
+    if (a.q_w) {
+      // QKV of the next block = y x W_in^T + bias.  A wave owns 48 of the 384 output channels for ALL rows of the tile: its 12 weight
+      // fragments (A operands, straight from the pack, no two waves fetch the same one) were requested before the row loop above; the rows
+      // (B operands) come from the 16-bit image just written.  96 MFMAs per wave.
+      __syncthreads();
+      f32x4 qb[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) qb[i] = *reinterpret_cast<const f32x4*>(a.q_bias + (wave * 3 + i) * 16 + g * 4);
+#pragma unroll 2
+      for (int j = 0; j < 8; ++j) {
+        const int row = j * 16 + r;
+        bf16x8 xb[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) xb[ks] = *reinterpret_cast<const bf16x8*>(stage + row * 512 + (((ks * 4 + g) ^ (row & 15)) << 4));
+        f32x4 acc[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc[i] = qb[i];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) acc[i] = DX_MFMA_H16(qa[i][ks], xb[ks], acc[i]);
+        if (row < len_cols) {
+          dx_h16* const orow = a.q_out + ((size_t)b * a.N + n0 + row) * 384 + wave * 48 + g * 4;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            bf16x4 o4;
+            o4[0] = (dx_h16)acc[i][0]; o4[1] = (dx_h16)acc[i][1]; o4[2] = (dx_h16)acc[i][2]; o4[3] = (dx_h16)acc[i][3];
+            *reinterpret_cast<bf16x4*>(orow + i * 16) = o4;
+          }
+        }
+      }
     }
   } else if (a.lnb_w) {
     // LayerNorm-backward epilogue (the block's first LayerNorm): same arithmetic as ln_bwd_kernel<128, float, false>
@@ -763,7 +817,10 @@ static int ff_pair_launch(const void* X, int ldx, const void* Wa, const void* Wb
   DX_REQUIRE(!aux || (ld_aux >= F && (ld_aux % 4) == 0), "dx_ff_pair: bad ld_aux");
   DX_REQUIRE((aux != nullptr) != (relu_mid != 0), "dx_ff_pair: exactly one of relu_mid (forward) and aux (backward) must be given");
   DX_REQUIRE(skip_halo < 0 || lens, "dx_ff_pair: skip_halo needs lens");
-  if (prologue) {
+  if (prologue && prologue->q_w) {
+    DX_REQUIRE(ln_w && prologue->q_bias && prologue->q_out && ((uintptr_t)prologue->q_w % 16) == 0 && ((uintptr_t)prologue->q_out % 16) == 0,
+               "dx_ff_pair_ln_qkv: needs the LayerNorm epilogue, a bias and 16-byte aligned pointers");
+  } else if (prologue) {
     DX_REQUIRE(lnb_w && prologue->lnp_dy && prologue->lnp_z && prologue->lnp_mean && prologue->lnp_rstd && prologue->lnp_w && prologue->lnp_b &&
                prologue->lnp_dg && prologue->lnp_dw && prologue->lnp_db, "dx_ff_block_bwd: null pointer");
     DX_REQUIRE((prologue->lnp_film == nullptr) == (prologue->lnp_dfilm == nullptr), "dx_ff_block_bwd: film and dfilm must come together");
@@ -775,8 +832,10 @@ static int ff_pair_launch(const void* X, int ldx, const void* Wa, const void* Wb
   FFPairArgs a{(const dx_h16*)X, ldx, (const dx_h16*)Wa, (const dx_h16*)Wb, bias_a, bias_b, (const dx_h16*)aux, ld_aux,
                (dx_h16*)H, ldh, Y, ldy, B, N, F, accumulate, lens, skip_halo, rows_exist,
                ln_res, ln_w, ln_b, film, ld_film, ln_y, ln_mean, ln_rstd, seed_pre, (unsigned)lrintf(p_pre * 65536.f), 1.f / (1.f - p_pre), seed_offset,
+               nullptr, nullptr, nullptr,
                lnb_z, lnb_mean, lnb_rstd, lnb_w, lnb_b, (dx_h16*)lnb_dg, lnb_dw, lnb_db};
-  if (prologue) {
+  if (prologue && prologue->q_w) { a.q_w = prologue->q_w; a.q_bias = prologue->q_bias; a.q_out = prologue->q_out; }
+  if (prologue && prologue->lnp_dy) {
     a.lnp_dy = prologue->lnp_dy; a.lnp_z = prologue->lnp_z; a.lnp_mean = prologue->lnp_mean; a.lnp_rstd = prologue->lnp_rstd;
     a.lnp_w = prologue->lnp_w; a.lnp_b = prologue->lnp_b; a.lnp_film = prologue->lnp_film; a.lnp_ld_film = prologue->lnp_ld_film;
     a.lnp_dg = prologue->lnp_dg; a.lnp_dw = prologue->lnp_dw; a.lnp_db = prologue->lnp_db; a.lnp_dfilm = prologue->lnp_dfilm;
@@ -821,6 +880,20 @@ int dx_ff_pair_ln(const void* X, int ldx, const void* Wa, const void* Wb, const 
   return ff_pair_launch(X, ldx, Wa, Wb, bias_a, bias_b, nullptr, 0, H, ldh, Z, 128, B, N, F, 1, 0, lens, skip_halo, rows_exist,
                         res, ln_w, ln_b, film, ld_film, Yln, mean, rstd, (unsigned long long)seed_pre, p_pre, (const unsigned long long*)seed_offset,
                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+// dx_ff_pair_ln + the NEXT block's attention in-projection on the normalised tile: QKV = Yln x Wq^T + bias_q (16-bit [B][N][384]; Wq: the
+// forward pack of the (384, 128) in-projection weight) -- the result of dx_conv_gemm(Yln, Wq, bias_q, taps = 1, lens, halo 0) without its launch
+int dx_ff_pair_ln_qkv(const void* X, int ldx, const void* Wa, const void* Wb, const float* bias_a, const float* bias_b, void* H, int ldh, float* Z,
+                      int B, int N, int F, const int* lens, int skip_halo, const int* rows_exist,
+                      const float* res, const float* ln_w, const float* ln_b, const float* film, int ld_film, float* Yln, float* mean, float* rstd,
+                      uint64_t seed_pre, float p_pre, const uint64_t* seed_offset, const void* Wq, const float* bias_q, void* QKV, void* stream) {
+  DX_REQUIRE(ln_w != nullptr && Wq != nullptr, "dx_ff_pair_ln_qkv: null pointer");
+  FFPairArgs ext{};
+  ext.q_w = (const dx_h16*)Wq; ext.q_bias = bias_q; ext.q_out = (dx_h16*)QKV;
+  return ff_pair_launch(X, ldx, Wa, Wb, bias_a, bias_b, nullptr, 0, H, ldh, Z, 128, B, N, F, 1, 0, lens, skip_halo, rows_exist,
+                        res, ln_w, ln_b, film, ld_film, Yln, mean, rstd, (unsigned long long)seed_pre, p_pre, (const unsigned long long*)seed_offset,
+                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ext, stream);
 }
 
 // The input-gradient pair with the backward of the block's FIRST LayerNorm folded into its epilogue:

@@ -151,7 +151,9 @@ class PaddedLinearFn(torch.autograd.Function):
 class FFTBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, film, lens, packs, cfg, training,
-                in_w, in_b, out_w, out_b, ln1_w, ln1_b, c1_w, c1_b, c2_w, c2_b, ln2_w, ln2_b):
+                in_w, in_b, out_w, out_b, ln1_w, ln1_b, c1_w, c1_b, c2_w, c2_b, ln2_w, ln2_b, qkv_pre=None, next_in=None):
+        """-> (y2, qkv_next).  ``qkv_pre``: this block's q/k/v, already produced by the previous block's last launch; ``next_in`` = (pack, bias)
+        of the next block's in-projection: where the fused feed-forward launch runs, it produces that block's q/k/v too (else None)."""
         p_attn = cfg['attn_dropout'] if training else 0.0
         p_conv = cfg['conv_dropout'] if training else 0.0
         heads = cfg['attn_nb_heads']
@@ -161,7 +163,8 @@ class FFTBlockFn(torch.autograd.Function):
         rt = packs['in'].rt
         prec = rt.precision                        # captured here, used by the backward (never re-read)
         hd = ops.hidden_dtype(prec)
-        qkv = ops.conv_gemm(x, packs['in'], in_b, lens=L, halo=0, out_dtype=hd, prec=prec)   # bf16 mode: attention reads bf16 q/k/v
+        qkv = qkv_pre if qkv_pre is not None else \
+            ops.conv_gemm(x, packs['in'], in_b, lens=L, halo=0, out_dtype=hd, prec=prec)     # bf16 mode: attention reads bf16 q/k/v
         so = rt.seed_offset                        # device scalar added to the seeds (graph replays), or None
         att, lse = ops.attention_fwd(qkv, lens.i32, heads, s_attn, p_attn, prec=prec, seed_offset=so, ctx_dtype=hd)   # 16-bit modes: 16-bit context
         sh = ops.gemm_shadow(prec)                 # bf16 mode: GEMM operands also exist as bf16 copies written by their producers
@@ -175,10 +178,13 @@ class FFTBlockFn(torch.autograd.Function):
             y1, mean1, rstd1 = ln1[:3]
             y1g = ln1[3] if sh else y1             # the copy the GEMMs read
         fused = ops.ff_pair_applies(y1g, packs['c1'], packs['c2'], prec)
-        y2 = None
+        y2 = qkv_next = None
         if fused and ops._FF_LN:   # ... and the block's second LayerNorm on the output tile while it is still in LDS
-            z2, h, y2, mean2, rstd2 = ops.ff_pair_ln(y1g, packs['c1'], packs['c2'], c1_b, c2_b, L, y1, ln2_w, ln2_b, film, seed_pre=s_ln2, p_pre=p_conv,
-                                                     seed_offset=so, prec=prec, rows_exist=lens.exist)
+            if next_in is not None and not ops.next_qkv_applies(next_in[0], prec):
+                next_in = None
+            z2, h, y2, mean2, rstd2, *rest = ops.ff_pair_ln(y1g, packs['c1'], packs['c2'], c1_b, c2_b, L, y1, ln2_w, ln2_b, film, seed_pre=s_ln2,
+                                                            p_pre=p_conv, seed_offset=so, prec=prec, rows_exist=lens.exist, next_in=next_in)
+            qkv_next = rest[0] if rest else None         # ... and the next block's in-projection on the normalised tile
         elif fused:    # conv1 + ReLU + conv2 in ONE launch, the 1024-wide hidden tile consumed from LDS (h is still written: weight gradients)
             z2, h = ops.ff_pair(y1g, packs['c1'], packs['c2'], c1_b, c2_b, L, prec=prec, rows_exist=lens.exist)
         else:
@@ -190,10 +196,12 @@ class FFTBlockFn(torch.autograd.Function):
         ctx.lens, ctx.packs, ctx.heads = lens, packs, heads
         ctx.drop = (p_attn, p_conv, s_attn, s_ln1, s_ln2)
         ctx.prec, ctx.sink, ctx.fused, ctx.seed_offset = prec, rt.sink, fused, so
-        return y2
+        if qkv_next is not None:
+            ctx.mark_non_differentiable(qkv_next)
+        return y2, qkv_next
 
     @staticmethod
-    def backward(ctx, dy2):
+    def backward(ctx, dy2, _dqkv_next=None):
         x, film, qkv, att, lse, z1, mean1, rstd1, y1, h, z2, mean2, rstd2, ln1_w, ln1_b, ln2_w, ln2_b = ctx.saved_tensors
         lens, packs = ctx.lens, ctx.packs
         if lens.exist is not None:
@@ -247,7 +255,7 @@ class FFTBlockFn(torch.autograd.Function):
         din_w, din_b = ops.conv_wgrad(dqkv, x, packs['in'], L, 0, arena=arena, w_sink=g('in_w'), b_sink=g('in_b'), prec=prec, defer=True)
         dx = ops.conv_gemm(dqkv, packs['in'], None, transpose=True, out=dz1, accumulate=True, lens=L, halo=0, prec=prec)  # + residual branch
         return (dx, dfilm, None, None, None, None,
-                din_w, din_b, dout_w, dout_b, dln1_w, dln1_b, dc1_w, dc1_b, dc2_w, dc2_b, dln2_w, dln2_b)
+                din_w, din_b, dout_w, dout_b, dln1_w, dln1_b, dc1_w, dc1_b, dc2_w, dc2_b, dln2_w, dln2_b, None, None)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -117,16 +117,30 @@ class FFTBlock(nn.Module):
         self.attention = MultiHeadAttention(cfg)
         self.feed_forward = PositionWiseConvFF(cfg)
 
-    def forward(self, x, film_params, lens: Lengths):
+    def forward(self, x, film_params, lens: Lengths, qkv_pre=None, next_block=None):
+        """-> (y, qkv_next): ``qkv_pre`` is this block's q/k/v when the previous block's last launch produced it; ``qkv_next`` the next
+        block's, when this block's fused feed-forward launch could produce it (else None)."""
         mha, ln1 = self.attention.multi_head_attention, self.attention.layer_norm
         c1, c2, ln2 = self.feed_forward.convs[0].conv, self.feed_forward.convs[2].conv, self.feed_forward.layer_norm
         packs = {'in': mha.in_pack, 'out': mha.out_proj.pack, 'c1': c1.pack, 'c2': c2.pack,
                  'params': {'in_w': mha.in_proj_weight, 'in_b': mha.in_proj_bias, 'out_w': mha.out_proj.weight, 'out_b': mha.out_proj.bias,
                             'ln1_w': ln1.weight, 'ln1_b': ln1.bias, 'c1_w': c1.weight, 'c1_b': c1.bias, 'c2_w': c2.weight, 'c2_b': c2.bias,
                             'ln2_w': ln2.weight, 'ln2_b': ln2.bias}}
+        nxt = None
+        if next_block is not None:
+            nm = next_block.attention.multi_head_attention
+            nxt = (nm.in_pack, nm.in_proj_bias)
         return Fx.FFTBlockFn.apply(x, film_params, lens, packs, self.cfg, self.training,
                                    mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias,
-                                   ln1.weight, ln1.bias, c1.weight, c1.bias, c2.weight, c2.bias, ln2.weight, ln2.bias)
+                                   ln1.weight, ln1.bias, c1.weight, c1.bias, c2.weight, c2.bias, ln2.weight, ln2.bias, qkv_pre, nxt)
+
+
+def _run_blocks(blocks, x, film, lens):
+    """The FFT blocks of one stack; a block's last launch hands the next block its q/k/v where it can (FFTBlock.forward)."""
+    qkv = None
+    for i, block in enumerate(blocks):
+        x, qkv = block(x, None if film is None else film[i], lens, qkv_pre=qkv, next_block=blocks[i + 1] if i + 1 < len(blocks) else None)
+    return x
 
 
 _PE_TABLES = {}
@@ -184,8 +198,7 @@ class AccentEncoder(nn.Module):
                                    c[8].conv.weight, c[8].conv.bias, c[10].weight, c[10].bias,
                                    self.energy_embedding.conv.weight, self.energy_embedding.conv.bias,
                                    self.pitch_embedding.conv.weight, self.pitch_embedding.conv.bias)
-        for block in self.blocks:
-            x = block(x, None, lens)
+        x = _run_blocks(self.blocks, x, None, lens)
         return Fx.MeanPoolFn.apply(x, lens, getattr(self, '_dx_rt', None))
 
 
@@ -306,9 +319,7 @@ class PhonemeEncoder(nn.Module):
         pe = positional_table(self.cfg['hidden_embed_dim'], x.device)
         h = Fx.EmbedPosFn.apply(x, self.symbols_embedding.weight, pe, lens, getattr(self, '_dx_rt', None))
         film = _film_blocks(film_params)
-        for i, block in enumerate(self.blocks):
-            h = block(h, None if film is None else film[i], lens)
-        return h
+        return _run_blocks(self.blocks, h, film, lens)
 
 
 class GaussianUpsamplingModule(nn.Module):
@@ -354,8 +365,7 @@ class FrameDecoder(nn.Module):
         pe = positional_table(self.cfg['hidden_embed_dim'], x.device)
         h = Fx.AddPosFn.apply(x, pe, lens)
         film = _film_blocks(film_params)
-        for i, block in enumerate(self.blocks):
-            h = block(h, film[i], lens)
+        h = _run_blocks(self.blocks, h, film, lens)
         p = self.projection.linear_layer
         return Fx.MelProjectionFn.apply(h, p.weight, p.bias, p.pack, lens)
 

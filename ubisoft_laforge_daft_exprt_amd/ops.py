@@ -308,10 +308,20 @@ def ff_pair(x, pack1: PackedWeight, pack2: PackedWeight, bias1, bias2, lens, *, 
 _FF_LN = os.environ.get('DX_FF_LN', '1') != '0'
 
 
+_FF_QKV = os.environ.get('DX_FF_QKV', '1') != '0'
+
+
+def next_qkv_applies(pack_in: PackedWeight, prec) -> bool:
+    """The next block's attention in-projection can ride in the ff_pair epilogue: 128 -> 384, one tap, a 16-bit operand mode."""
+    return _FF_QKV and _half(prec) == 1 and pack_in.taps == 1 and pack_in.cin == 128 and pack_in.cout == 384
+
+
 def ff_pair_ln(x, pack1: PackedWeight, pack2: PackedWeight, bias1, bias2, lens, res, ln_w, ln_b, film, *, seed_pre=0, p_pre=0.0, seed_offset=None,
-               halo=1, prec=None, rows_exist=None):
+               halo=1, prec=None, rows_exist=None, next_in=None):
     """The forward pair with the block's second LayerNorm folded into its epilogue (dx_ff_pair_ln).  Returns (z, h, y, mean, rstd):
-    z = res + dropout(pair output) [fp32, what ln_fwd leaves in its input], y = mask(FiLM(LN(z)))."""
+    z = res + dropout(pair output) [fp32, what ln_fwd leaves in its input], y = mask(FiLM(LN(z))).
+    ``next_in`` = (PackedWeight, bias) of the NEXT block's attention in-projection: the launch also produces that block's qkv
+    (dx_ff_pair_ln_qkv) and a sixth value, the 16-bit (B, N, 384) tensor, is returned."""
     prec = pack1.rt.precision if prec is None else prec
     B, N, D = x.shape
     Fc = pack1.cout
@@ -322,6 +332,14 @@ def ff_pair_ln(x, pack1: PackedWeight, pack2: PackedWeight, bias1, bias2, lens, 
     mean = torch.empty(B, N, dtype=torch.float32, device=x.device)
     rstd = torch.empty(B, N, dtype=torch.float32, device=x.device)
     _log(pack1, ('ffpair', B * N, N, 128, Fc, 3))
+    if next_in is not None:
+        pq, bq = next_in
+        qkv = torch.empty(B, N, 384, dtype=_H16[prec], device=x.device)
+        _log(pq, ('conv', B * N, N, 128, 384, 1))
+        _fn('dx_ff_pair_ln_qkv', prec)(_p(x), _rows(x), _p(i1.fwd), _p(i2.fwd), _p(bias1), _p(bias2), _p(h), _rows(h), _p(z), B, N, Fc, _p(lens), int(halo),
+                                       _p(rows_exist), _p(res), _p(ln_w), _p(ln_b), _p(film), 0 if film is None else film.stride(0), _p(y), _p(mean),
+                                       _p(rstd), seed_pre, float(p_pre), _p(seed_offset), _p(pq.image(prec).fwd), _p(bq), _p(qkv), _stream())
+        return z, h, y, mean, rstd, qkv
     _fn('dx_ff_pair_ln', prec)(_p(x), _rows(x), _p(i1.fwd), _p(i2.fwd), _p(bias1), _p(bias2), _p(h), _rows(h), _p(z), B, N, Fc, _p(lens), int(halo),
                                _p(rows_exist), _p(res), _p(ln_w), _p(ln_b), _p(film), 0 if film is None else film.stride(0), _p(y), _p(mean), _p(rstd),
                                seed_pre, float(p_pre), _p(seed_offset), _stream())

@@ -71,6 +71,11 @@ def price(name, a, geom: Geometry):
         F = a['F']
         byt = rows * (128 * 2 + F * 2 + 128 * 4 * 3 + 8) + 2 * 3 * 128 * F * 2
         return 'ff_pair_kernel<fwd>', 'mfma', 2.0 * 2 * 3 * 128 * F * rows, byt
+    if name == 'dx_ff_pair_ln_qkv':                      # ... + the next block's in-projection (128 -> 384) on the normalised tile: 16-bit qkv written
+        rows = geom.rows(a['B'], a['N'], has('lens'))
+        F = a['F']
+        byt = rows * (128 * 2 + F * 2 + 128 * 4 * 3 + 8 + 384 * 2) + 2 * 3 * 128 * F * 2 + 384 * 128 * 2
+        return 'ff_pair_kernel<fwd>', 'mfma', (2.0 * 2 * 3 * 128 * F + 2.0 * 128 * 384) * rows, byt
     if name == 'dx_ff_pair_lnbwd':                       # the input-gradient pair + the LayerNorm-backward epilogue: z read, dz and the 16-bit copy written
         rows = geom.rows(a['B'], a['N'], has('lens'))
         F = a['F']
