@@ -19,17 +19,24 @@ constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
 
 __device__ __forceinline__ float softplus_ref(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
-// one block per utterance: exclusive cumsum of integer durations (int64), means, total frames
+// one wave per utterance: exclusive cumsum of integer durations (int64, exact), means, total frames.  (A single thread walking the row
+// paid one dependent-load latency per symbol: 17 us for L = 120.)
 __global__ __launch_bounds__(64) void dur_scan_kernel(const long* __restrict__ dur_int, float* __restrict__ mu, long* __restrict__ totals, int L) {
-  const int b = blockIdx.x;
-  if (threadIdx.x != 0) return;
-  long run = 0;
-  for (int l = 0; l < L; ++l) {
-    const long d = dur_int[(size_t)b * L + l];
-    mu[(size_t)b * L + l] = (float)d / 2.f + (float)run;   // dur_int.float()/2 + cumsum[:-1] (model.py:485-487)
-    run += d;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  long carry = 0;
+  for (int base = 0; base < L; base += 64) {
+    const int l = base + lane;
+    const long d = l < L ? dur_int[(size_t)b * L + l] : 0;
+    long inc = d;                                            // inclusive prefix over the 64 lanes
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const long v = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += v;
+    }
+    if (l < L) mu[(size_t)b * L + l] = (float)d / 2.f + (float)(carry + inc - d);   // dur_int.float()/2 + cumsum[:-1] (model.py:485-487)
+    carry += __shfl(inc, 63, 64);
   }
-  totals[b] = run;
+  if (lane == 0) totals[b] = carry;
 }
 
 struct PrepArgs {
