@@ -235,14 +235,23 @@ def test_deep_k_conv_path(ops, Cin, Cout, taps, x_bf16):
             yb = ops.conv_gemm(xin, pack, b, relu=True, post_scale=sc, post_shift=sh, relu_aux=aux, lens=lens, halo=1, out_dtype=torch.bfloat16,
                                out_scale=0.5)
             refb = (F.relu(ref) * sc + sh) * 0.5 * (aux.float() > 0)
-            keep = (torch.arange(N, device=DEV)[None, :, None] < ((lens[:, None, None] + 1 + 127) // 128) * 128)
-            assert yb.dtype == torch.bfloat16 and rel_err(yb.float() * keep, refb * keep) < 2e-2
-            assert torch.equal(yb.float() * ~keep, torch.zeros_like(refb))
+            # the contract of skip_halo: rows below len + halo are computed; whole tiles beyond them are zero-filled.  The tile is the
+            # kernel's own business (128 tokens, 64 in the short-token kernel): rows between len + halo and the next 128 boundary may be either
+            n_ax = torch.arange(N, device=DEV)[None, :, None]
+            must, beyond = n_ax < lens[:, None, None] + 1, n_ax >= ((lens[:, None, None] + 1 + 127) // 128) * 128
+            assert yb.dtype == torch.bfloat16 and rel_err(yb.float() * must, refb * must) < 2e-2
+            assert torch.equal(yb.float() * beyond, torch.zeros_like(refb))
+            between = ~must & ~beyond
+            assert bool(((yb.float() == 0) | ((yb.float() - refb).abs() <= 2e-2 * refb.abs().max()))[between.expand_as(refb)].all())
         acc0 = randn(B, N, Cout, seed=6)
         ya = ops.conv_gemm(xin, pack, None, out=acc0.clone(), accumulate=True, lens=lens, halo=0)
-        tiles_ok = (torch.arange(N, device=DEV)[None, :, None] < ((lens[:, None, None] + 127) // 128) * 128)
-        assert rel_err(ya * tiles_ok, (acc0 + ref_conv(xr, w, None, taps)) * tiles_ok) < 1e-2
-        assert torch.equal(ya * ~tiles_ok, acc0 * ~tiles_ok)
+        n_ax = torch.arange(N, device=DEV)[None, :, None]
+        must, beyond = n_ax < lens[:, None, None], n_ax >= ((lens[:, None, None] + 127) // 128) * 128
+        full = acc0 + ref_conv(xr, w, None, taps)
+        assert rel_err(ya * must, full * must) < 1e-2
+        assert torch.equal(ya * beyond, acc0 * beyond)
+        between = (~must & ~beyond).expand_as(full)
+        assert bool(((ya == acc0) | ((ya - full).abs() <= 1e-2 * full.abs().max()))[between].all())       # untouched, or accumulated
     finally:
         ops.set_precision('f32')
 
