@@ -198,6 +198,7 @@ class FFTBlockFn(torch.autograd.Function):
         ctx.prec, ctx.sink, ctx.fused, ctx.seed_offset = prec, rt.sink, fused, so
         if qkv_next is not None:
             ctx.mark_non_differentiable(qkv_next)
+        ctx.set_materialize_grads(False)           # else autograd hands backward a zero tensor the size of qkv_next (33 MB fill per block)
         return y2, qkv_next
 
     @staticmethod
@@ -347,6 +348,7 @@ class FilmAffineFn(torch.autograd.Function):
         ctx.nb, ctx.rt, ctx.has_pm = nb, rt, pm is not None
         whole = film.detach()                      # (nb, B, 2C): for the (B, nb, 2C) tensors of the reference's outputs[1] (strided views, no copy)
         ctx.mark_non_differentiable(whole)
+        ctx.set_materialize_grads(False)           # blocks without a gradient arrive as None (film_affine_bwd skips them), not as zero fills
         return tuple(film[i] for i in range(nb)) + (whole,)
 
     @staticmethod
@@ -416,6 +418,7 @@ class GaussianUpsampleFn(torch.autograd.Function):
         ctx.sink = bool(rt is not None and rt.sink)
         ctx.rt = rt
         ctx.mark_non_differentiable(weights)
+        ctx.set_materialize_grads(False)           # no 20 MB zero tensor for the alignment's (unused) gradient slot
         return xup, weights
 
     @staticmethod

@@ -125,6 +125,7 @@ class _LossFn(torch.autograd.Function):
             d_pm = d_pm.view_as(post_multipliers)
         ctx.save_for_backward(dmel, d_spk, d_pm)
         ctx.mark_non_differentiable(terms)
+        ctx.set_materialize_grads(False)
         return total, terms
 
     @staticmethod
