@@ -139,7 +139,7 @@ class PaddedLinearFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         dyp = ops._zeros(ctx.pack.rt.arena, dy.shape[0], ctx.pack.cout, device=dy.device)
         dyp[:, :ctx.cout].copy_(dy)
-        dw, db = ops.conv_wgrad(dyp, x, ctx.pack, prec=ctx.prec)
+        dw, db = ops.conv_wgrad(dyp, x, ctx.pack, arena=ctx.pack.rt.arena, prec=ctx.prec)
         dw, db = dw[:ctx.cout], db[:ctx.cout]
         dx = ops.conv_gemm(dyp, ctx.pack, None, transpose=True, prec=ctx.prec)
         return dx, dw, db, None
