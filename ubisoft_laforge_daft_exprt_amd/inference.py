@@ -113,7 +113,7 @@ class GraphedSynthesizer:
                         self._device_forward({**static, **meta})
                     torch.cuda.current_stream().wait_stream(stream)
                     graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph):
+                    with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                         outs = self._device_forward({**static, **meta})
                     self._evict(self.graphs, self.max_graphs)
                     entry = dict(graph=graph, static=static, outs=outs, hits=0)
@@ -167,7 +167,7 @@ class GraphedSynthesizer:
                     run(*args())
                 torch.cuda.current_stream().wait_stream(stream)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                     out = run(*args())
                 self._evict(self.accent_graphs, self.max_graphs)
                 entry = dict(graph=graph, static=static, out=out, hits=0)

@@ -145,11 +145,12 @@ class Trainer:
             pb()
         torch.cuda.current_stream().wait_stream(side)
         g.graph_a, g.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g.graph_a):
+        # thread_local: CUDA calls of OTHER threads (the RCCL watchdog polling its events, a pinned-memory loader) must not abort the capture
+        with torch.cuda.graph(g.graph_a, capture_error_mode='thread_local'):
             rt.seed_offset.add_(1)                            # a new dropout stream per replay (the seeds in the launches are frozen)
             g.loss, terms, phase_b = self._phases(static, self.adv_weight, lambda gid: None)
         g.terms_dev = [t._device_terms for t in terms]        # static device tensors: wrapped anew after every replay
-        with torch.cuda.graph(g.graph_b, pool=g.graph_a.pool()):
+        with torch.cuda.graph(g.graph_b, pool=g.graph_a.pool(), capture_error_mode='thread_local'):
             phase_b()
         g.inputs, g.hits = static, 0
         if len(self.graphs) >= self.max_graphs:               # evict the least used shape (its pool is freed with it)
