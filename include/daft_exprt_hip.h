@@ -101,6 +101,8 @@ int dx_ff_pair(const void* X, int ldx, const void* Wa, const void* Wb, const flo
  * is normalised while it is in LDS.  Z = res + dropout(pair output) (fp32 [B][N][128], what dx_ln_fwd leaves in `a`), Yln / mean / rstd /
  * film / seeds as in dx_ln_fwd with C = 128 and halo 0 (rows >= lens[b] are masked); lens is required; skip_halo as in dx_ff_pair (it
  * only decides which whole tiles are computed: the hidden rows of the halo are still written to H for the weight gradients). */
+/* H may be NULL in the forward entry points (dx_ff_pair with relu_mid, dx_ff_pair_ln, dx_ff_pair_ln_qkv): the mid activation is then not
+ * written (inference: nothing reads it; 2 KB per token saved). */
 int dx_ff_pair_ln(const void* X, int ldx, const void* Wa, const void* Wb, const float* bias_a, const float* bias_b, void* H, int ldh, float* Z,
                   int B, int N, int F, const int* lens, int skip_halo, const int* rows_exist,
                   const float* res, const float* ln_w, const float* ln_b, const float* film, int ld_film, float* Yln, float* mean, float* rstd,

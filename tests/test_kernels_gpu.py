@@ -569,6 +569,9 @@ def test_ff_pair_epilogue_produces_next_blocks_qkv(ops, precision):
             for a, b in ((z0, z1), (m0, m1), (r0, r1)):              # (tiles beyond the halo leave these three unwritten)
                 assert torch.equal(a[valid], b[valid])
             assert q1.dtype == h16 and q1.shape == (B, N, 384)
+            # forward-only form (inference): no hidden tensor, everything else bit for bit
+            z2, h2, y2, m2, r2, q2 = ops.ff_pair_ln(x, p1, p2, b1, b2, lens, res, lw, lb, film, seed_pre=91, p_pre=0.1, next_in=(pq, bq), need_h=False)
+            assert h2 is None and torch.equal(y2, y1) and torch.equal(q2, q1) and torch.equal(z2[valid], z1[valid]) and torch.equal(m2[valid], m1[valid])
             ulp = 2.0 ** -7 if precision == 'bf16' else 2.0 ** -10
             diff = (q1.float() - q0.float()).abs()[valid]              # (padded rows: the two launches tile the axis differently, see below)
             assert float((diff / q0.float()[valid].abs().clamp_min(0.25)).max()) <= 2 * ulp   # at most a rounding step of the 16-bit result

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
 
   if (!live) {                                        // padding beyond the halo: nobody reads it with a non-zero weight; keep it defined
     const int rows = min(FP_TOK, a.N - n0);
-    const int hu = a.F >> 3;                          // 16-byte units per hidden row
+    const int hu = a.H ? a.F >> 3 : 0;                // 16-byte units per hidden row (no hidden output in a forward-only call)
     for (int u = tid; u < rows * hu; u += 512) {
       const int row = u / hu, q = u - row * hu;
       *reinterpret_cast<f32x4*>(a.H + ((size_t)b * a.N + n0 + row) * a.ldh + q * 8) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -377,6 +377,7 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) foff[t][hh] = fp_lds_off(r + t, hh * 4 + g);
   const int len_cols = min(FP_TOK, a.N - n0);         // output columns of this tile that exist
+  const int h_rows = a.H ? len_cols : 0;              // rows of the mid activation to write out (none in a forward-only call: H == null)
 
   // Copy-out of the slice completed in the previous iteration (hidden rows 1..126 of the image <-> tokens n0 .. n0+125), as
   // full 128-byte row segments: piece K of 4 per thread, read from LDS in one matrix step and stored in the next (standalone it
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
   {                                                                                                                  \
     const int u_ = fp_opaque(tid) + 1024 + (K) * 256;                                                                \
     const int row_ = u_ >> 4, q_ = u_ & 15;                                                                          \
-    if (row_ < len_cols) *reinterpret_cast<f32x4*>(a.H + ((size_t)b * a.N + n0 + row_) * a.ldh + (F0C) + q_ * 8) = cpv; \
+    if (row_ < h_rows) *reinterpret_cast<f32x4*>(a.H + ((size_t)b * a.N + n0 + row_) * a.ldh + (F0C) + q_ * 8) = cpv; \
   }
 #define FP_COPY_OUT_CONS(IMGC, F0C)                                                                                  \
   {                                                                                                                  \
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
     _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                                  \
       const int u_ = t_ + k * 256;                                                                                   \
       const int row_ = u_ >> 4, q_ = u_ & 15;                                                                        \
-      if (row_ < len_cols) *reinterpret_cast<f32x4*>(a.H + ((size_t)b * a.N + n0 + row_) * a.ldh + (F0C) + q_ * 8) = cv_[k]; \
+      if (row_ < h_rows) *reinterpret_cast<f32x4*>(a.H + ((size_t)b * a.N + n0 + row_) * a.ldh + (F0C) + q_ * 8) = cv_[k]; \
     }                                                                                                                \
   }
 
@@ -800,7 +801,8 @@ static int ff_pair_launch(const void* X, int ldx, const void* Wa, const void* Wb
                           float* ln_y, float* ln_mean, float* ln_rstd, unsigned long long seed_pre, float p_pre, const unsigned long long* seed_offset,
                           const float* lnb_z, const float* lnb_mean, const float* lnb_rstd, const float* lnb_w, const float* lnb_b,
                           void* lnb_dg, float* lnb_dw, float* lnb_db, const FFPairArgs* prologue, void* stream) {
-  DX_REQUIRE((X || prologue) && Wa && Wb && H && Y, "dx_ff_pair: null pointer");
+  DX_REQUIRE((X || prologue) && Wa && Wb && Y, "dx_ff_pair: null pointer");
+  DX_REQUIRE(H || (relu_mid && !lnb_w), "dx_ff_pair: only the forward pair may omit the mid-activation output H");
   if (ln_w) {
     DX_REQUIRE(relu_mid && !accumulate && lens && skip_halo >= 0 && ldy == 128, "dx_ff_pair_ln: forward pair, no accumulate, lens, dense Z");
     DX_REQUIRE(ln_res && ln_b && ln_y && ln_mean && ln_rstd, "dx_ff_pair_ln: null pointer");

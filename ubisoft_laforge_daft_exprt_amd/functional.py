@@ -183,7 +183,8 @@ class FFTBlockFn(torch.autograd.Function):
             if next_in is not None and not ops.next_qkv_applies(next_in[0], prec):
                 next_in = None
             z2, h, y2, mean2, rstd2, *rest = ops.ff_pair_ln(y1g, packs['c1'], packs['c2'], c1_b, c2_b, L, y1, ln2_w, ln2_b, film, seed_pre=s_ln2,
-                                                            p_pre=p_conv, seed_offset=so, prec=prec, rows_exist=lens.exist, next_in=next_in)
+                                                            p_pre=p_conv, seed_offset=so, prec=prec, rows_exist=lens.exist, next_in=next_in,
+                                                            need_h=any(ctx.needs_input_grad))     # inference: the 2 KB/token hidden tensor is not written
             qkv_next = rest[0] if rest else None         # ... and the next block's in-projection on the normalised tile
         elif fused:    # conv1 + ReLU + conv2 in ONE launch, the 1024-wide hidden tile consumed from LDS (h is still written: weight gradients)
             z2, h = ops.ff_pair(y1g, packs['c1'], packs['c2'], c1_b, c2_b, L, prec=prec, rows_exist=lens.exist)

@@ -317,16 +317,17 @@ def next_qkv_applies(pack_in: PackedWeight, prec) -> bool:
 
 
 def ff_pair_ln(x, pack1: PackedWeight, pack2: PackedWeight, bias1, bias2, lens, res, ln_w, ln_b, film, *, seed_pre=0, p_pre=0.0, seed_offset=None,
-               halo=1, prec=None, rows_exist=None, next_in=None):
+               halo=1, prec=None, rows_exist=None, next_in=None, need_h=True):
     """The forward pair with the block's second LayerNorm folded into its epilogue (dx_ff_pair_ln).  Returns (z, h, y, mean, rstd):
     z = res + dropout(pair output) [fp32, what ln_fwd leaves in its input], y = mask(FiLM(LN(z))).
     ``next_in`` = (PackedWeight, bias) of the NEXT block's attention in-projection: the launch also produces that block's qkv
-    (dx_ff_pair_ln_qkv) and a sixth value, the 16-bit (B, N, 384) tensor, is returned."""
+    (dx_ff_pair_ln_qkv) and a sixth value, the 16-bit (B, N, 384) tensor, is returned.
+    ``need_h=False`` (forward-only calls): the hidden tensor is not written and ``h`` is returned as None."""
     prec = pack1.rt.precision if prec is None else prec
     B, N, D = x.shape
     Fc = pack1.cout
     i1, i2 = pack1.image(prec), pack2.image(prec)
-    h = torch.empty(B, N, Fc, dtype=_H16[prec], device=x.device)
+    h = torch.empty(B, N, Fc, dtype=_H16[prec], device=x.device) if need_h else None
     z = torch.empty(B, N, 128, dtype=torch.float32, device=x.device)
     y = torch.empty_like(z)
     mean = torch.empty(B, N, dtype=torch.float32, device=x.device)
@@ -336,11 +337,11 @@ def ff_pair_ln(x, pack1: PackedWeight, pack2: PackedWeight, bias1, bias2, lens, 
         pq, bq = next_in
         qkv = torch.empty(B, N, 384, dtype=_H16[prec], device=x.device)
         _log(pq, ('conv', B * N, N, 128, 384, 1))
-        _fn('dx_ff_pair_ln_qkv', prec)(_p(x), _rows(x), _p(i1.fwd), _p(i2.fwd), _p(bias1), _p(bias2), _p(h), _rows(h), _p(z), B, N, Fc, _p(lens), int(halo),
+        _fn('dx_ff_pair_ln_qkv', prec)(_p(x), _rows(x), _p(i1.fwd), _p(i2.fwd), _p(bias1), _p(bias2), _p(h), Fc if h is None else _rows(h), _p(z), B, N, Fc, _p(lens), int(halo),
                                        _p(rows_exist), _p(res), _p(ln_w), _p(ln_b), _p(film), 0 if film is None else film.stride(0), _p(y), _p(mean),
                                        _p(rstd), seed_pre, float(p_pre), _p(seed_offset), _p(pq.image(prec).fwd), _p(bq), _p(qkv), _stream())
         return z, h, y, mean, rstd, qkv
-    _fn('dx_ff_pair_ln', prec)(_p(x), _rows(x), _p(i1.fwd), _p(i2.fwd), _p(bias1), _p(bias2), _p(h), _rows(h), _p(z), B, N, Fc, _p(lens), int(halo),
+    _fn('dx_ff_pair_ln', prec)(_p(x), _rows(x), _p(i1.fwd), _p(i2.fwd), _p(bias1), _p(bias2), _p(h), Fc if h is None else _rows(h), _p(z), B, N, Fc, _p(lens), int(halo),
                                _p(rows_exist), _p(res), _p(ln_w), _p(ln_b), _p(film), 0 if film is None else film.stride(0), _p(y), _p(mean), _p(rstd),
                                seed_pre, float(p_pre), _p(seed_offset), _stream())
     return z, h, y, mean, rstd
