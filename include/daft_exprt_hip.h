@@ -54,6 +54,9 @@ int dx_pack_weights(const float* W, void* fwd, void* bwd, int Cout, int Cin, int
 /* every layer of a model in one launch; descs = device array of n 56-byte records
  * {const float* W; void* fwd; void* bwd; int32 Cout, Cin, taps, CoutP_f, CinP_f, CinP_b, CoutP_b, pad} */
 int dx_pack_weights_batched(const void* descs, int n, int bf16, void* stream);
+/* the same from a HOST array of the records: the descriptors travel as kernel arguments (chunks of 60 layers) and the grid holds one
+ * wave per 16 x 32 block of the whole model -- what an optimiser step is followed by (one launch for the 57 packed layers of DaftExprt) */
+int dx_pack_weights_host(const void* descs, int n, int bf16, void* stream);
 /* Y[b,n,:] = out_scale * mask( relu_aux>0 ? . : 0 )( post_scale * relu?( bias + conv(X) ) + post_shift )  (+= if accumulate)
  * taps 1 (Linear) or 3 (zero 'same' padding inside each batch row).  NULL disables an epilogue stage.
  * skip_halo >= 0: 128-token tiles that start at or beyond lens[b] + skip_halo are padding nobody reads: zero-filled, not computed

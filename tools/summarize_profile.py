@@ -31,7 +31,7 @@ LABELS = [
     ('add_pos', r'add_pos_kernel'), ('accent_sum', r'accent_sum_kernel'), ('scalar_conv_wgrad', r'scalar_conv_wgrad_kernel'),
     ('transpose', r'transpose_kernel'), ('mask_rows', r'mask_rows_kernel'), ('mean_pool', r'mean_pool_kernel'),
     ('mean_pool_bwd', r'mean_pool_bwd_kernel'), ('channel_affine', r'channel_affine_kernel'), ('relu_bwd', r'relu_bwd_kernel'),
-    ('colsum', r'colsum_kernel'), ('pack_weights_batched', r'pack_weights_batched'),
+    ('colsum', r'colsum_kernel'), ('pack_weights_batched', r'pack_weights_batched|pack_weights_flat'),
 ]
 
 

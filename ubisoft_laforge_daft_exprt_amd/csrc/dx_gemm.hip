@@ -1425,51 +1425,78 @@ __global__ void pack_weights_batched_kernel(const PackDesc* __restrict__ descs) 
 // checkpoint with a 12-byte stride once per tap: 105 us per step for 57 MB of weights).  Lane = (row r, k-group g): forward
 // blocks read 8 consecutive input channels x taps (96 B contiguous per lane, 4 lanes per row), backward blocks (rows = input
 // channels, k = output channels, taps flipped) read 8 output-channel rows at one input channel.
-__global__ __launch_bounds__(256) void pack_weights_batched_bf16_kernel(const PackDesc* __restrict__ descs) {
-  const PackDesc d = descs[blockIdx.y];
+// one 16-row x 32-k block (all taps) of descriptor d: blk < nfb forward, else backward
+__device__ __forceinline__ void pack_block_bf16(const PackDesc& d, int blk, int lane) {
   dx_h16* fwd = reinterpret_cast<dx_h16*>(d.fwd);
   dx_h16* bwd = reinterpret_cast<dx_h16*>(d.bwd);
-  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int r = lane & 15, g = lane >> 4;
   const int fkb = d.CinP_f >> 5, nfb = (d.CoutP_f >> 4) * fkb;          // forward blocks per tap
   const int bkb = d.CoutP_b >> 5, nbb = bwd ? (d.CinP_b >> 4) * bkb : 0;
-  for (int blk = blockIdx.x * 4 + (threadIdx.x >> 6); blk < nfb + nbb; blk += gridDim.x * 4) {
-    if (blk < nfb) {
-      const int co = (blk / fkb) * 16 + r, ci = (blk % fkb) * 32 + g * 8;
-      float v[3][8];
+  if (blk < nfb) {
+    const int co = (blk / fkb) * 16 + r, ci = (blk % fkb) * 32 + g * 8;
+    // all 24 loads are unconditional (indices clamped, zeros selected in afterwards): a load inside a lane-dependent branch makes the
+    // compiler wait for each one before the next (24 round trips per wave: this kernel took 68 us for 115 MB)
+    float v[3][8];
+    const int tl = d.taps - 1;
+    const size_t rowb = (size_t)min(co, d.Cout - 1) * d.Cin;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const bool in = co < d.Cout && ci + e < d.Cin;
+    for (int e = 0; e < 8; ++e)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) v[t][e] = (in && t < d.taps) ? d.W[((size_t)co * d.Cin + ci + e) * d.taps + t] : 0.f;
-      }
+      for (int t = 0; t < 3; ++t) v[t][e] = d.W[(rowb + min(ci + e, d.Cin - 1)) * d.taps + min(t, tl)];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        if (t >= d.taps) break;
-        bf16x8 h;
+    for (int t = 0; t < 3; ++t) {
+      if (t >= d.taps) break;
+      bf16x8 h;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) h[e] = (dx_h16)v[t][e];
-        *reinterpret_cast<bf16x8*>(fwd + ((size_t)t * nfb + blk) * 512 + lane * 8) = h;
-      }
-    } else {
-      const int bb = blk - nfb;
-      const int ci = (bb / bkb) * 16 + r, co = (bb % bkb) * 32 + g * 8;
-      float v[3][8];
+      for (int e = 0; e < 8; ++e) h[e] = (dx_h16)((co < d.Cout && ci + e < d.Cin) ? v[t][e] : 0.f);
+      *reinterpret_cast<bf16x8*>(fwd + ((size_t)t * nfb + blk) * 512 + lane * 8) = h;
+    }
+  } else if (blk < nfb + nbb) {
+    const int bb = blk - nfb;
+    const int ci = (bb / bkb) * 16 + r, co = (bb % bkb) * 32 + g * 8;
+    float v[3][8];
+    const int tl = d.taps - 1, cic = min(ci, d.Cin - 1);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const bool in = ci < d.Cin && co + e < d.Cout;
+    for (int e = 0; e < 8; ++e)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) v[t][e] = (in && t < d.taps) ? d.W[((size_t)(co + e) * d.Cin + ci) * d.taps + t] : 0.f;
-      }
+      for (int t = 0; t < 3; ++t) v[t][e] = d.W[((size_t)min(co + e, d.Cout - 1) * d.Cin + cic) * d.taps + min(t, tl)];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        if (t >= d.taps) break;
-        bf16x8 h;
+    for (int t = 0; t < 3; ++t) {
+      if (t >= d.taps) break;
+      bf16x8 h;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) h[e] = (dx_h16)(d.taps == 3 ? v[2 - t][e] : v[0][e]);    // taps flipped
-        *reinterpret_cast<bf16x8*>(bwd + ((size_t)t * nbb + bb) * 512 + lane * 8) = h;
-      }
+      for (int e = 0; e < 8; ++e) h[e] = (dx_h16)((ci < d.Cin && co + e < d.Cout) ? (d.taps == 3 ? v[2 - t][e] : v[0][e]) : 0.f);    // taps flipped
+      *reinterpret_cast<bf16x8*>(bwd + ((size_t)t * nbb + bb) * 512 + lane * 8) = h;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void pack_weights_batched_bf16_kernel(const PackDesc* __restrict__ descs) {
+  const PackDesc d = descs[blockIdx.y];
+  const int fkb = d.CinP_f >> 5, nfb = (d.CoutP_f >> 4) * fkb;
+  const int bkb = d.CoutP_b >> 5, nbb = d.bwd ? (d.CinP_b >> 4) * bkb : 0;
+  for (int blk = blockIdx.x * 4 + (threadIdx.x >> 6); blk < nfb + nbb; blk += gridDim.x * 4) pack_block_bf16(d, blk, threadIdx.x & 63);
+}
+
+// The same work with the descriptors as KERNEL ARGUMENTS and a flat grid: one wave per block of the whole model.  The form above
+// launches 512 workgroups per layer whatever its size (layers differ by four orders of magnitude) and every workgroup starts with a
+// global round trip for its descriptor: 29 k workgroups, most of which fetch a descriptor and leave - 71 us per step for 115 MB.
+constexpr int PACK_MAX = 60;          // 60 x 56 B + prefix: 3.6 KB of the 4 KB argument segment (the runtime's hidden arguments take 256 B)
+struct PackBatchArgs {
+  PackDesc d[PACK_MAX];
+  int prefix[PACK_MAX + 1];          // exclusive prefix of blocks per descriptor; prefix[n] = total
+  int n;
+};
+static_assert(sizeof(PackBatchArgs) <= 3712, "kernel arguments must stay under the 4 KB limit");
+__global__ __launch_bounds__(256) void pack_weights_flat_bf16_kernel(const PackBatchArgs a) {
+  const int wb = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: scalar loads from the argument block
+  if (wb >= a.prefix[a.n]) return;
+  int lo = 0, hi = a.n;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (a.prefix[mid] <= wb) lo = mid; else hi = mid;
+  }
+  pack_block_bf16(a.d[lo], wb - a.prefix[lo], threadIdx.x & 63);
 }
 
 // grad[co][ci][tap] (+)= G[tap][co][ci]
@@ -1570,6 +1597,35 @@ int dx_pack_weights_batched(const void* descs, int n, int bf16, void* stream) {
   if (bf16) hipLaunchKernelGGL(pack_weights_batched_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs);
   else hipLaunchKernelGGL(pack_weights_batched_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs);
   DX_LAUNCH_CHECK("dx_pack_weights_batched");
+  return DX_OK;
+}
+
+// descs: HOST array of n 56-byte records (as above).  16-bit packs: the descriptors travel as kernel arguments (no device table) and the
+// grid holds one wave per 16 x 32 block of the whole model; exact-f32 packs: the records are staged through a small device table.
+int dx_pack_weights_host(const void* descs, int n, int bf16, void* stream) {
+  DX_REQUIRE(descs && n > 0, "dx_pack_weights_host: bad arguments");
+  const PackDesc* h = reinterpret_cast<const PackDesc*>(descs);
+  hipStream_t s = (hipStream_t)stream;
+  if (!bf16) {
+    for (int i = 0; i < n; ++i)
+      if (int rc = dx_pack_weights(h[i].W, h[i].fwd, h[i].bwd, h[i].Cout, h[i].Cin, h[i].taps, 0, stream)) return rc;
+    return DX_OK;
+  }
+  for (int base = 0; base < n; base += PACK_MAX) {
+    PackBatchArgs a{};
+    a.n = std::min(PACK_MAX, n - base);
+    int run = 0;
+    for (int i = 0; i < a.n; ++i) {
+      const PackDesc& d = h[base + i];
+      DX_REQUIRE(d.W && d.fwd && d.Cout > 0 && d.Cin > 0 && (d.taps == 1 || d.taps == 3), "dx_pack_weights_host: bad descriptor %d", base + i);
+      a.d[i] = d;
+      a.prefix[i] = run;
+      run += (d.CoutP_f >> 4) * (d.CinP_f >> 5) + (d.bwd ? (d.CinP_b >> 4) * (d.CoutP_b >> 5) : 0);
+    }
+    a.prefix[a.n] = run;
+    hipLaunchKernelGGL(pack_weights_flat_bf16_kernel, dim3(dx_cdiv(run, 4)), dim3(256), 0, s, a);
+  }
+  DX_LAUNCH_CHECK("dx_pack_weights_host");
   return DX_OK;
 }
 

@@ -156,14 +156,14 @@ def repack_all(rt=None, packs=None) -> int:
         return 0
     sig = (prec,) + tuple((pk.weight.data_ptr(), img.fwd.data_ptr(), img.bwd.data_ptr()) for pk, img in stale)
     table = rt._tables.get(sig)
-    if table is None:                      # the descriptor table only changes when buffers are (re)allocated: upload it once
+    if table is None:                      # the descriptor records only change when buffers are (re)allocated: build them once (host memory)
         recs = b''.join(struct.pack('<QQQ8i', pk.weight.data_ptr(), img.fwd.data_ptr(), img.bwd.data_ptr(), pk.cout, pk.cin, pk.taps,
                                      img.dims[0], img.dims[1], img.dims[2], img.dims[3], 0) for pk, img in stale)
-        table = torch.frombuffer(bytearray(recs), dtype=torch.uint8).to(stale[0][0].weight.device)
+        table = ctypes.create_string_buffer(recs, len(recs))
         if len(rt._tables) > 8:
             rt._tables.clear()
         rt._tables[sig] = table
-    _fn('dx_pack_weights_batched', prec)(_p(table), len(stale), _half(prec), _stream())
+    _fn('dx_pack_weights_host', prec)(ctypes.addressof(table), len(stale), _half(prec), _stream())     # descriptors travel as kernel arguments
     for pk, img in stale:
         img.key = pk._current_key()
     return len(stale)
