@@ -1661,7 +1661,8 @@ int dx_conv_gemm(const void* Xv, int ldx, const void* Wp, const float* bias, voi
   static const int use_dk = getenv("DX_CONV_DK") ? atoi(getenv("DX_CONV_DK")) : 1;
   static const int ws_min_tiles = getenv("DX_CONV_WS_MIN_TILES") ? atoi(getenv("DX_CONV_WS_MIN_TILES")) : 64;
   // deep-K layers: weights straight from the fragment-major pack into registers, live tiles numbered first
-  if (bf16 && use_dk && d[1] >= 256 && (Cin % 64) == 0 && (long)B * N * ldx < (1L << 31)) {
+  static const int dk_min_cin = getenv("DX_CONV_DK_MIN_CIN") ? atoi(getenv("DX_CONV_DK_MIN_CIN")) : 256;
+  if (bf16 && use_dk && d[1] >= dk_min_cin && (Cin % 64) == 0 && (long)B * N * ldx < (1L << 31)) {
     if (x_bf16) { if (taps == 3) launch_conv_dk<3, true>(a, s); else launch_conv_dk<1, true>(a, s); }
     else { if (taps == 3) launch_conv_dk<3, false>(a, s); else launch_conv_dk<1, false>(a, s); }
   } else if (bf16 && use_ws && d[1] == 128 && (long)B * dx_cdiv(N, 128) >= ws_min_tiles) {      // short-K layers: weight-stationary persistent kernel
