@@ -848,7 +848,8 @@ int dx_ln_bwd(const void* dyv, const void* zv, const float* mean, const float* r
   // Measured at C2 (frame axis, 43 k rows): C = 128: 4 waves x 64 rows 25.4 us, 16 waves x 256 rows 23.6, 16 x 192 21.4; C = 1024: 4 x 64 94 us, 4 x 96 78
   const bool big = big_env && C == 128 && (long)B * N >= 16384;
   static const int rpb_1024 = getenv("DX_LN_BWD_RPB_1024") ? atoi(getenv("DX_LN_BWD_RPB_1024")) : 32;   // 96 / 48 / 32 / 24 rows: 6.363 / 6.350 / 6.345 / 6.351 ms per step
-  const int rpb = rpb_env > 0 ? rpb_env : (big ? 192 : (C == 1024 ? rpb_1024 : 64));
+  static const int rpb_small = getenv("DX_LN_BWD_RPB_SMALL") ? atoi(getenv("DX_LN_BWD_RPB_SMALL")) : 64;
+  const int rpb = rpb_env > 0 ? rpb_env : (big ? 192 : (C == 1024 ? rpb_1024 : rpb_small));
   LnBwdArgs k{dy, z, mean, rstd, w, bias, film, ld_film, lens, halo, dz, da, (dx_h16*)dg_bf16_copy, dw, dbias, dfilm, ld_dfilm, B, N, rpb, relu_mask,
               seed_pre, (uint32_t)lrintf(p_pre * 65536.f), 1.f / (1.f - p_pre),
               seed_post, (uint32_t)lrintf(p_post * 65536.f), 1.f / (1.f - p_post), seed_offset};
