@@ -199,7 +199,7 @@ int dx_scalar_conv_wgrad(const float* dout, int ldd, const float* rowscale, cons
                          float* dw0, float* db0, float* dw1, float* db1, int B, int N, int D, void* stream);
 int dx_mean_pool(const float* x, const int* lens, float* out, int B, int N, int C, void* stream);
 int dx_mean_pool_bwd(const float* dout, const int* lens, float* dx, int B, int N, int C, void* stream);
-int dx_transpose(const float* in, float* out, int B, int R, int Cc, void* stream);
+int dx_transpose(const float* in, float* out, int B, int R, int Cc, int accumulate, void* stream);   /* accumulate: out += in^T */
 int dx_relu_bwd(const float* dy, const float* y, float* out, long n, void* stream);
 int dx_channel_affine(const void* x, const float* scale, const float* shift, void* out, long rows, int C, int io_bf16, void* stream); /* layers/pitch_predictor.py:49-62 (BatchNorm1d, eval); io_bf16: x / out stored in the mode's 16-bit type */
 int dx_l2_normalize(const float* x, float* y, int rows, int C, void* stream);            /* model.py:904 */
@@ -233,8 +233,8 @@ int dx_loss_finalize(const float* ce, const float* spk_w_dev, float spk_w, const
                      const float* pm, float* d_pm, int n_pm, float pmw,
                      const float* l1sum, const float* l2sum, const int* lens, int B, int M, float msw,
                      const float* esum, float ecw, const float* psum, float pcw, float* terms, float* total, void* stream);
-int dx_pitch_mse(const float* pp, const float* gt, const int* lens, float* sums, int B, int T, void* stream);
-int dx_pitch_grad(const float* pp, const float* gt, const int* lens, const float* sums, float scale, float* dpp, int B, int T, void* stream);
+int dx_pitch_mse(const float* pp, int ldp, const float* gt, const int* lens, float* sums, int B, int T, void* stream);   /* ldp / ldd: element stride between consecutive frames of pp / dpp (the predictor's last conv writes 4-wide rows, channel 0 is the prediction) */
+int dx_pitch_grad(const float* pp, int ldp, const float* gt, const int* lens, const float* sums, float scale, float* dpp, int ldd, int B, int T, void* stream);
 
 /* ---- on-device batch conditioning: dynamic_stats.py:131-195 ------------------------------------------------ */
 int dx_condition_prosody(const float* in, float* out, const long* speaker_ids, const float* table, const int* valid,

@@ -105,14 +105,14 @@ __global__ __launch_bounds__(256) void mel_grad_kernel(const float* __restrict__
 }
 
 // sums[0] += sum mask (pp - gt)^2, sums[1] += sum mask;  mask = t < len and gt != 0
-__global__ __launch_bounds__(256) void pitch_mse_kernel(const float* __restrict__ pp, const float* __restrict__ gt, const int* __restrict__ lens,
+__global__ __launch_bounds__(256) void pitch_mse_kernel(const float* __restrict__ pp, int ldp, const float* __restrict__ gt, const int* __restrict__ lens,
                                                         float* __restrict__ sums, int T) {
   __shared__ float scratch[4];
   const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
   float e = 0.f, n = 0.f;
   if (t < T) {
     const float g = gt[(size_t)b * T + t];
-    if (t < lens[b] && g != 0.f) { const float d = pp[(size_t)b * T + t] - g; e = d * d; n = 1.f; }
+    if (t < lens[b] && g != 0.f) { const float d = pp[((size_t)b * T + t) * ldp] - g; e = d * d; n = 1.f; }
   }
   const float se = block_sum_256(e, scratch);
   const float sn = block_sum_256(n, scratch);
@@ -120,14 +120,14 @@ __global__ __launch_bounds__(256) void pitch_mse_kernel(const float* __restrict_
 }
 
 // dpp = scale * 2 (pp - gt) mask / (count + 1e-5)
-__global__ __launch_bounds__(256) void pitch_grad_kernel(const float* __restrict__ pp, const float* __restrict__ gt, const int* __restrict__ lens,
-                                                         const float* __restrict__ sums, float scale, float* __restrict__ dpp, int T) {
+__global__ __launch_bounds__(256) void pitch_grad_kernel(const float* __restrict__ pp, int ldp, const float* __restrict__ gt, const int* __restrict__ lens,
+                                                         const float* __restrict__ sums, float scale, float* __restrict__ dpp, int ldd, int T) {
   const int b = blockIdx.y, t = blockIdx.x * 256 + threadIdx.x;
   if (t >= T) return;
   const float g = gt[(size_t)b * T + t];
   float v = 0.f;
-  if (t < lens[b] && g != 0.f) v = scale * 2.f * (pp[(size_t)b * T + t] - g) / (sums[1] + 1e-5f);
-  dpp[(size_t)b * T + t] = v;
+  if (t < lens[b] && g != 0.f) v = scale * 2.f * (pp[((size_t)b * T + t) * ldp] - g) / (sums[1] + 1e-5f);
+  dpp[((size_t)b * T + t) * ldd] = v;
 }
 
 // The seven loss terms and the total (loss.py:85-157) from the reductions above, plus the two small gradients, in one block:
@@ -211,16 +211,16 @@ int dx_loss_finalize(const float* ce, const float* spk_w_dev, float spk_w, const
   return DX_OK;
 }
 
-int dx_pitch_mse(const float* pp, const float* gt, const int* lens, float* sums, int B, int T, void* stream) {
-  DX_REQUIRE(pp && gt && lens && sums && B > 0 && T > 0, "dx_pitch_mse: bad arguments");
-  hipLaunchKernelGGL(pitch_mse_kernel, dim3(dx_cdiv(T, 256), B), dim3(256), 0, (hipStream_t)stream, pp, gt, lens, sums, T);
+int dx_pitch_mse(const float* pp, int ldp, const float* gt, const int* lens, float* sums, int B, int T, void* stream) {
+  DX_REQUIRE(pp && ldp >= 1 && gt && lens && sums && B > 0 && T > 0, "dx_pitch_mse: bad arguments");
+  hipLaunchKernelGGL(pitch_mse_kernel, dim3(dx_cdiv(T, 256), B), dim3(256), 0, (hipStream_t)stream, pp, ldp, gt, lens, sums, T);
   DX_LAUNCH_CHECK("dx_pitch_mse");
   return DX_OK;
 }
 
-int dx_pitch_grad(const float* pp, const float* gt, const int* lens, const float* sums, float scale, float* dpp, int B, int T, void* stream) {
-  DX_REQUIRE(pp && gt && lens && sums && dpp && B > 0 && T > 0, "dx_pitch_grad: bad arguments");
-  hipLaunchKernelGGL(pitch_grad_kernel, dim3(dx_cdiv(T, 256), B), dim3(256), 0, (hipStream_t)stream, pp, gt, lens, sums, scale, dpp, T);
+int dx_pitch_grad(const float* pp, int ldp, const float* gt, const int* lens, const float* sums, float scale, float* dpp, int ldd, int B, int T, void* stream) {
+  DX_REQUIRE(pp && ldp >= 1 && gt && lens && sums && dpp && ldd >= 1 && B > 0 && T > 0, "dx_pitch_grad: bad arguments");
+  hipLaunchKernelGGL(pitch_grad_kernel, dim3(dx_cdiv(T, 256), B), dim3(256), 0, (hipStream_t)stream, pp, ldp, gt, lens, sums, scale, dpp, ldd, T);
   DX_LAUNCH_CHECK("dx_pitch_grad");
   return DX_OK;
 }

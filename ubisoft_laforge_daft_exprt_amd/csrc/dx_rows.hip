@@ -613,7 +613,7 @@ __global__ __launch_bounds__(256) void mean_pool_bwd_kernel(const float* __restr
 }
 
 // batched transpose in[b][R][Cc] -> out[b][Cc][R]
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc) {
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc, int accumulate) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z;
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
   __syncthreads();
   for (int k = ty; k < 32; k += 8) {
     const int c = c0 + k, r = r0 + tx;
-    if (c < Cc && r < R) ob[(size_t)c * R + r] = tile[tx][k];
+    if (c < Cc && r < R) ob[(size_t)c * R + r] = accumulate ? ob[(size_t)c * R + r] + tile[tx][k] : tile[tx][k];
   }
 }
 
@@ -942,9 +942,9 @@ int dx_mean_pool_bwd(const float* dout, const int* lens, float* dx, int B, int N
   return DX_OK;
 }
 
-int dx_transpose(const float* in, float* out, int B, int R, int Cc, void* stream) {
+int dx_transpose(const float* in, float* out, int B, int R, int Cc, int accumulate, void* stream) {
   DX_REQUIRE(in && out && B > 0 && R > 0 && Cc > 0, "dx_transpose: bad arguments");
-  hipLaunchKernelGGL(transpose_kernel, dim3(dx_cdiv(Cc, 32), dx_cdiv(R, 32), B), dim3(256), 0, (hipStream_t)stream, in, out, R, Cc);
+  hipLaunchKernelGGL(transpose_kernel, dim3(dx_cdiv(Cc, 32), dx_cdiv(R, 32), B), dim3(256), 0, (hipStream_t)stream, in, out, R, Cc, accumulate);
   DX_LAUNCH_CHECK("dx_transpose");
   return DX_OK;
 }

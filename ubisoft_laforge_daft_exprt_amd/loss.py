@@ -105,19 +105,17 @@ class _LossFn(torch.autograd.Function):
                 acts.append(r)
                 x = ops.channel_affine(r, layer['scale'], layer['shift'], prec=prec)
             last = pitch_layers[-1]
-            pp = ops.conv_gemm(x, last['pack'], last['b'], lens=lens.i32, halo=0, prec=prec)[:, :, 0].contiguous()  # (B, T)
+            pp = ops.conv_gemm(x, last['pack'], last['b'], lens=lens.i32, halo=0, prec=prec)      # (B, T, 4): channel 0 is the prediction
             frames_pitch = frames_pitch.contiguous()
-            psum = ops.pitch_mse(pp, frames_pitch, lens.i32, arena=arena)
-            dpp = ops.pitch_grad(pp, frames_pitch, lens.i32, psum, cfg['pcw'])
-            g = ops._zeros(arena, B, T, 4, device=dev)
-            g[:, :, 0] = dpp
+            psum = ops.pitch_mse(pp, frames_pitch, lens.i32, arena=arena)                          # (read and written in place: no slice copies)
+            g = ops.pitch_grad(pp, frames_pitch, lens.i32, psum, cfg['pcw'], out=ops._zeros(arena, B, T, 4, device=dev))
             # each input-gradient GEMM applies the previous layer's BatchNorm scale and ReLU mask in its epilogue
             for k in range(len(pitch_layers) - 1, 0, -1):
                 prev = pitch_layers[k - 1]
                 g = ops.conv_gemm(g, pitch_layers[k]['pack'], None, transpose=True, post_scale=prev['scale'], post_shift=prev['zeros'],
                                   relu_aux=acts[k - 1], lens=lens.i32, halo=depth - k + 1, prec=prec, out_dtype=hd)
             d = ops.conv_gemm(g, pitch_layers[0]['pack'], None, transpose=True, lens=lens.i32, halo=0, prec=prec)
-            dmel = dmel + ops.transpose(d)
+            dmel = ops.transpose(d, add_to=dmel)                                   # dmel is this function's own fresh tensor
         # the seven terms, the total and the two small gradients: one launch (was ~30 one-element ATen launches)
         terms, total, d_spk, d_pm = ops.loss_finalize(ce, dlogits, cfg['spk_weight'], pm, cfg['pmw'], sums, lens.i32, M, cfg['msw'],
                                                       esum, cfg['ecw'], psum, cfg['pcw'])

@@ -682,11 +682,11 @@ def mean_pool_bwd(dout, lens, N):
     return dx
 
 
-def transpose(x):
-    """(B, R, C) -> (B, C, R), contiguous."""
+def transpose(x, add_to=None):
+    """(B, R, C) -> (B, C, R), contiguous.  ``add_to``: a contiguous (B, C, R) tensor that the transpose is ADDED to in place (returned)."""
     B, R, C = x.shape
-    out = torch.empty(B, C, R, dtype=torch.float32, device=x.device)
-    lib().dx_transpose(_p(x), _p(out), B, R, C, _stream())
+    out = add_to if add_to is not None else torch.empty(B, C, R, dtype=torch.float32, device=x.device)
+    lib().dx_transpose(_p(x), _p(out), B, R, C, int(add_to is not None), _stream())
     return out
 
 
@@ -791,17 +791,24 @@ def loss_finalize(ce, dlogits, spk_w, pm, pmw, sums, lens, M, msw, esum, ecw, ps
     return out[:7], out[7], d_spk, d_pm
 
 
+def _frame_stride(t):
+    """(B, T) contiguous -> 1; (B, T, C) contiguous -> C (channel 0 of every row is meant)."""
+    return 1 if t.dim() == 2 else t.shape[2]
+
+
 def pitch_mse(pp, gt, lens, arena=None):
+    """``pp``: (B, T), or the (B, T, C) output of the predictor's last convolution (channel 0 is read in place)."""
     B, T = gt.shape
     sums = _zeros(arena, 2, device=gt.device)
-    lib().dx_pitch_mse(_p(pp), _p(gt), _p(lens), _p(sums), B, T, _stream())
+    lib().dx_pitch_mse(_p(pp), _frame_stride(pp), _p(gt), _p(lens), _p(sums), B, T, _stream())
     return sums
 
 
-def pitch_grad(pp, gt, lens, sums, scale):
+def pitch_grad(pp, gt, lens, sums, scale, out=None):
+    """``out``: optional (B, T, C) tensor whose channel 0 receives the gradient (the other channels are left as they are)."""
     B, T = gt.shape
-    dpp = torch.empty(B, T, dtype=torch.float32, device=gt.device)
-    lib().dx_pitch_grad(_p(pp), _p(gt), _p(lens), _p(sums), float(scale), _p(dpp), B, T, _stream())
+    dpp = out if out is not None else torch.empty(B, T, dtype=torch.float32, device=gt.device)
+    lib().dx_pitch_grad(_p(pp), _frame_stride(pp), _p(gt), _p(lens), _p(sums), float(scale), _p(dpp), _frame_stride(dpp), B, T, _stream())
     return dpp
 
 
