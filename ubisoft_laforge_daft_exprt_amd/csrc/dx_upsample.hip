@@ -99,12 +99,17 @@ template <int TT>
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const UpArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wt = smem;                       // [L][TT]
-  float* part = smem + (size_t)a.L * TT;  // [4][TT]
+  float* part = smem + (size_t)a.L * TT;  // [256 / TT][TT]
+  float* lgs = part + 256;                // [L] log(sigma_l)
+  float* two = lgs + a.L;                 // [L] 2 sigma_l^2
   const int b = blockIdx.y, t0 = blockIdx.x * TT;
   const int tid = threadIdx.x;
   const int len = a.lens[b];
   const float* mu = a.mu + (size_t)b * a.L;
   const float* sg = a.sigma + (size_t)b * a.L;
+  // per-symbol terms of the log-density once per workgroup instead of once per (symbol, frame): the same values, so the same bits
+  for (int l = tid; l < a.L; l += 256) { const float sd = sg[min(l, max(len, 1) - 1)]; lgs[l] = logf(sd); two[l] = 2.f * (sd * sd); }
+  __syncthreads();
   // pass 1: probabilities into LDS, column sums
   {
     constexpr int LG = 256 / TT;          // symbol groups walking l in parallel
@@ -114,8 +119,8 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const UpArgs a) {
     for (int l = lg; l < a.L; l += LG) {
       float p = 0.f;
       if (l < len) {
-        const float sd = sg[l], d = tv - mu[l];
-        p = expf(-(d * d) / (2.f * (sd * sd)) - logf(sd) - LOG_SQRT_2PI);
+        const float d = tv - mu[l];
+        p = expf(-(d * d) / two[l] - lgs[l] - LOG_SQRT_2PI);
       }
       wt[(size_t)l * TT + tt] = p;
       s += p;
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(256) void upsample_sym_bwd_kernel(const SymBwdArgs 
   if (threadIdx.x == 0) atomicAdd(&a.dbr[0], (redb[0] + redb[1]) + (redb[2] + redb[3]));
 }
 
-template <int TT> size_t fwd_smem(int L) { return ((size_t)L * TT + (size_t)(256 / TT) * TT) * sizeof(float); }
+template <int TT> size_t fwd_smem(int L) { return ((size_t)L * TT + (size_t)(256 / TT) * TT + 2 * (size_t)L) * sizeof(float); }
 template <int TT> size_t bwd_smem(int L) {
   const size_t Lp = (size_t)((L + 15) & ~15);
   return ((size_t)TT * (D + 4) + ((Lp * (TT + 1) + 3) & ~(size_t)3) + Lp * (TT + 4) + 256 + std::max<size_t>(32 * (D + 4), (size_t)D * (TT + 4))) * sizeof(float);
