@@ -145,36 +145,46 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const UpArgs a) {
     __syncthreads();
   }
   // pass 2: x_up[t][c] = sum_l w[l][t] * xs[l][c]
-  if constexpr (TT == 16) {
+  if constexpr (TT == 16 || TT == 32) {
     // on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32, exact fp32 products): A = xs^T (m = channel, k = symbol), B = w (k = symbol,
     // n = frame), both operands read as they lie (row-major xs from L1 / L2, the probability tile from LDS) - one scalar each per MFMA.
-    // A wave owns 32 channels x the tile's 16 frames; two accumulator chains per channel tile.  (As FMA loops: 120 iterations of one
+    // A wave owns 32 channels x the tile's frames; two accumulator chains per 16 x 16 tile.  (As FMA loops: 120 iterations of one
     // global load, two LDS reads and eight FMAs per thread.)
+    constexpr int NT = TT / 16;
     const int lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
     const float* xb = a.xs + (size_t)b * a.L * D;
     const int lmax = min(len, a.L);
     const int nk = ((lmax + 3) >> 2) + 1 & ~1;                     // k steps of 4 symbols, rounded up to a pair
-    f32x4 acc00 = f32x4{0.f, 0.f, 0.f, 0.f}, acc01 = acc00, acc10 = acc00, acc11 = acc00;
+    f32x4 acc[2][NT][2];                                           // [channel tile][frame tile][chain]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) { acc[i][j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][j][1] = acc[i][j][0]; }
     const int c0 = wave * 32 + r;
     for (int kb = 0; kb < nk; kb += 2) {
-      const int l0 = kb * 4 + g, l1 = l0 + 4;
-      const bool in0 = l0 < lmax, in1 = l1 < lmax;
-      const int q0 = min(l0, max(lmax, 1) - 1), q1 = min(l1, max(lmax, 1) - 1);      // clamped: no load sits in a branch
-      const float w0 = wt[(size_t)q0 * TT + r], w1 = wt[(size_t)q1 * TT + r];
-      const float x00 = xb[(size_t)q0 * D + c0], x01 = xb[(size_t)q0 * D + c0 + 16];
-      const float x10 = xb[(size_t)q1 * D + c0], x11 = xb[(size_t)q1 * D + c0 + 16];
-      const float b0 = in0 ? w0 : 0.f, b1 = in1 ? w1 : 0.f;
-      acc00 = __builtin_amdgcn_mfma_f32_16x16x4f32(x00, b0, acc00, 0, 0, 0);
-      acc10 = __builtin_amdgcn_mfma_f32_16x16x4f32(x01, b0, acc10, 0, 0, 0);
-      acc01 = __builtin_amdgcn_mfma_f32_16x16x4f32(x10, b1, acc01, 0, 0, 0);
-      acc11 = __builtin_amdgcn_mfma_f32_16x16x4f32(x11, b1, acc11, 0, 0, 0);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int l = (kb + h) * 4 + g;
+        const bool in = l < lmax;
+        const int q = min(l, max(lmax, 1) - 1);                    // clamped: no load sits in a branch
+        const float x0 = xb[(size_t)q * D + c0], x1 = xb[(size_t)q * D + c0 + 16];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float wv = wt[(size_t)q * TT + j * 16 + r];
+          const float bw = in ? wv : 0.f;
+          acc[0][j][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, bw, acc[0][j][h], 0, 0, 0);
+          acc[1][j][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, bw, acc[1][j][h], 0, 0, 0);
+        }
+      }
     }
-    const int t = t0 + r;                                           // D[m = channel 4g + e][n = frame r]
-    if (t < a.T) {
-      float* orow = a.xup + ((size_t)b * a.T + t) * D + wave * 32 + g * 4;
-      const f32x4 o0 = acc00 + acc01, o1 = acc10 + acc11;
-      *reinterpret_cast<f32x4*>(orow) = o0;
-      *reinterpret_cast<f32x4*>(orow + 16) = o1;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int t = t0 + j * 16 + r;                                // D[m = channel 4g + e][n = frame r]
+      if (t < a.T) {
+        float* orow = a.xup + ((size_t)b * a.T + t) * D + wave * 32 + g * 4;
+        *reinterpret_cast<f32x4*>(orow) = acc[0][j][0] + acc[0][j][1];
+        *reinterpret_cast<f32x4*>(orow + 16) = acc[1][j][0] + acc[1][j][1];
+      }
     }
   } else {
     constexpr int TH = TT / 2;
