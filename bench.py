@@ -91,6 +91,8 @@ def main():
     ap.add_argument('--kernel-table', default='', help='write the per-kernel roofline table of the last timed step to this JSON file')
     ap.add_argument('--no-graph', action='store_true', help='issue every launch from Python instead of replaying the two captured HIP graphs')
     ap.add_argument('--no-dropout', action='store_true', help='diagnostic only: the headline metric is measured with dropout on')
+    ap.add_argument('--cuts', default='auto', help="backward phases of the trainer: 'auto' (3 cuts when N > 1, none on one GPU) or 0..3")
+    ap.add_argument('--no-extras', action='store_true', help='skip the sustained run, the f32-mode step and the C4 inference batch that follow the timed region')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -145,15 +147,15 @@ def main():
     dev_batch = tuple(t.to(dev) if torch.is_tensor(t) else t for t in batch)
     for i in (5, 9):
         dev_batch[i]._dx_host_lengths = batch[i].tolist()
-    trainer = Trainer(model, crit, hp, use_graphs=not args.no_graph)
+    trainer = Trainer(model, crit, hp, use_graphs=not args.no_graph, cuts=args.cuts if args.cuts == 'auto' else int(args.cuts))
     dev_batch = trainer.resident_batch(dev_batch)      # the graphs' static input buffers ARE the resident batch
     ev_bwd = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev_red = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     _orig_finish = trainer.reducer.finish
 
     def step(it, timed_idx=None):
-        # Trainer.train_step: [graph A: zero buckets, forward, loss, backward part 1] -> all-reduce group 0 (async) ->
-        # [graph B: accent-encoder backward] -> all-reduce group 1 -> wait -> fused Adam (clip, LR schedule) -> one-launch re-pack
+        # Trainer.train_step: per backward phase [one captured graph] -> that phase's all-reduce group (async, RCCL's stream), the next
+        # phase running beside it; one phase on one GPU, four when N > 1 -> wait -> fused Adam (clip, LR schedule) -> one-launch re-pack
         if timed_idx is not None:
             def finish():
                 ev_bwd[timed_idx].record()
@@ -213,13 +215,17 @@ def main():
         mfma = [(k, v) for k, v in table.items() if v['bound'] == 'mfma']
         if mfma:
             k, v = mfma[0]                                            # the single kernel with the most time in the step
-            traffic = None
-            pmc = os.path.join(REPO, 'profiles', 'r02_pmc_traffic.json')
-            if os.path.exists(pmc):
-                with open(pmc) as f:
-                    traffic = json.load(f).get(args.precision, {}).get(k, {}).get('hbm_bytes_per_launch')
+            traffic = traffic_source = None
+            for pmc_name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json'):      # PMC counters need rocprofv3: collected by tools/collect_profiles.sh, committed
+                pmc = os.path.join(REPO, 'profiles', pmc_name)
+                if os.path.exists(pmc):
+                    with open(pmc) as f:
+                        traffic = json.load(f).get(args.precision, {}).get(k, {}).get('hbm_bytes_per_launch')
+                    if traffic is not None:
+                        traffic_source = f'profiles/{pmc_name} (committed; rocprofv3 --pmc passes of this command, not measured in this run)'
+                        break
             roofline = {'bound': 'mfma', 'kernel': k, 'achieved': v['achieved'], 'peak': v['peak'], 'unit': 'TFLOP/s', 'frac': v['frac'],
-                        'traffic': traffic, 'algorithmic_bytes_per_launch': v['algorithmic_bytes_per_launch'], 'launches': v['launches'],
+                        'traffic': traffic, 'traffic_source': traffic_source, 'algorithmic_bytes_per_launch': v['algorithmic_bytes_per_launch'], 'launches': v['launches'],
                         'avg_launch_us': v['avg_us'], 'share_of_step': round(v['total_us'] / step_us, 3),
                         'measured_on': 'events around every launch of this kernel in the last timed step',
                         'other_mfma_kernels': {kk: {'frac': vv['frac'], 'achieved': vv['achieved'], 'launches': vv['launches'], 'avg_us': vv['avg_us'],
@@ -238,6 +244,70 @@ def main():
             with open(args.kernel_table, 'w') as f:
                 json.dump({'precision': args.precision, 'config': args.config, 'ms_per_step': 1e3 * elapsed / args.steps, 'kernels': table}, f, indent=1)
 
+    # ---- what follows the timed region: numbers that used to exist only in builder-run files -------------------------
+    extras = {}
+    ms_step = 1e3 * elapsed / args.steps
+    if not args.no_extras:
+        # (1) sustained: the same captured step replayed for >= 2 s (the timed region above is a 0.13 s burst; clocks sag under
+        #     sustained MFMA load).  Every rank takes part (the step contains the collectives); the count comes from the max-over-ranks time.
+        n_sus = max(args.steps, int(2000.0 / ms_step) + 1)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for it in range(n_sus):
+            step(args.warmup + args.steps + it)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        sus = time.perf_counter() - ts
+        extras['sustained'] = {'seconds': round(sus, 3), 'steps': n_sus, 'ms_per_step': round(1e3 * sus / n_sus, 3),
+                               'value': round(total_frames * n_sus / sus, 1)}
+    if not args.no_extras and world == 1 and rank == 0:
+        # (2) the parity mode (exact-f32 MFMA operands: the mode that meets the 1e-4 mel-L1 bar), same batch, same trainer structure
+        if args.precision != 'f32':
+            pkg.set_precision('f32')
+            try:
+                m32 = pkg.DaftExprt(hp).to(dev)
+                m32.load_state_dict(synthetic_state_dict({k: tuple(v.shape) for k, v in m32.state_dict().items()}, 1234), strict=True)
+                c32 = pkg.DaftExprtLoss(dev, hp)
+                c32.load_pitch_predictor(synthetic_state_dict(pitch_predictor_shapes(), 1235))
+            finally:
+                pkg.set_precision(args.precision)
+            t32 = Trainer(m32, c32, hp, use_graphs=not args.no_graph, cuts=args.cuts if args.cuts == 'auto' else int(args.cuts))
+            b32 = t32.resident_batch(dev_batch)
+            for _ in range(2):
+                t32.train_step([b32])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(8):
+                l32, _, _ = t32.train_step([b32])
+            torch.cuda.synchronize()
+            d32 = (time.perf_counter() - t1) / 8
+            assert torch.isfinite(l32).item()
+            extras['f32_mode'] = {'ms_per_step': round(1e3 * d32, 3), 'value': round(frames / d32, 1), 'steps': 8, 'warmup': 2,
+                                  'note': 'exact-f32 MFMA operands everywhere: the mode whose forward meets mel L1 <= 1e-4 vs the reference'}
+            del t32, m32, c32, b32
+        # (3) config 4: inference, 256 sentences per batch, bucketed graph replay, inputs resident + the batched reference-recording leg
+        sys.path.insert(0, os.path.join(REPO, 'tools'))
+        import bench_inference
+        inf = bench_inference.measure(args.precision, 8, n=10, warm=2)
+        extras['inference_c4'] = {'ms_per_batch': inf['graph_replay']['ms_per_batch'], 'frames_per_s': inf['graph_replay']['frames_per_s'],
+                                  'accent_leg_ms': inf['accent_encoder_leg']['batched_graph']['ms'], 'end_to_end_frames_per_s': inf['end_to_end_graph']['frames_per_s'],
+                                  'B': inf['B'], 'T_max': inf['T_max'], 'valid_frames': inf['valid_frames'], 'host_prepare_ms': inf['host_prepare_ms'],
+                                  'precision': args.precision, 'launch': 'bucketed hipGraph replay, inputs resident in HBM'}
+    # (4) parity of the measured mode on the measured shape, from the last committed GPU test record (tests/test_configs_gpu.py)
+    parity = None
+    import glob
+    recs = sorted(glob.glob(os.path.join(REPO, 'profiles', f'r*_parity_{args.config.lower()}_{args.precision}.json')))
+    if recs:
+        with open(recs[-1]) as f:
+            pr = json.load(f)
+        parity = {'mode': args.precision, 'mel_l1_vs_oracle': pr.get('mel_l1'), 'bar_in_test': pr.get('bar_mel_l1'),
+                  'north_star_bar': 1e-4, 'meets_north_star_bar': bool(pr.get('mel_l1', 1.0) <= 1e-4),
+                  'worst_grad_rel': pr.get('worst_grad_rel'), 'worst_grad_cos': pr.get('worst_grad_cos'),
+                  'source': 'profiles/' + os.path.basename(recs[-1]) + ' (tests/test_configs_gpu.py on MI355X)'}
+
     if rank == 0:
         result = {
             'metric': 'mel frames/sec (fwd+bwd)', 'value': round(total_frames * args.steps / elapsed, 1), 'unit': 'valid mel frames/s',
@@ -253,11 +323,15 @@ def main():
                        'operands': (f'{args.precision} MFMA operands for Conv1d/Linear GEMMs and attention, fp32 accumulate; 1024-wide hidden tensors, qkv, '
                                     f'attention context and their gradients stored {args.precision}' + (', static loss scale 4096' if args.precision == 'fp16' else ''))
                                    if args.precision != 'f32' else 'exact f32 MFMA everywhere',
-                       'parallelism': f'dp{world}', 'launch': 'eager (one Python call per kernel)' if args.no_graph else 'two captured HIP graphs per step + eager optimiser'},
+                       'parallelism': f'dp{world}', 'launch': 'eager (one Python call per kernel)' if args.no_graph else f'{trainer.cut_levels + 1} captured HIP graph(s) per step (one per backward phase) + eager optimiser'},
         }
         result['rccl_ranks'] = dist.get_world_size() if world > 1 else 1
         result['exposed_allreduce_ms_per_step'] = round(exposed_ms, 4)
         result['host_enqueue_ms_per_step'] = round(1e3 * host_s / args.steps, 3)
+        result['exchange'] = trainer.exchange_plan()     # per group: bytes, launch point; exposed_bytes = the group launched after the last backward kernel
+        result.update(extras)
+        if parity is not None:
+            result['parity'] = parity
         if roofline is not None:
             result['roofline'] = roofline
         if roofline_hbm:

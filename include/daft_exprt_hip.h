@@ -243,8 +243,13 @@ int dx_gather_speaker_rows(const float* emb, const long* speaker_ids, const int*
 
 /* ---- fused optimiser step: train.py:278-280 (Adam), :443 (clip_grad_norm_) ------------------------------ */
 int dx_sumsq(const float* x, long n, float* out, void* stream);
+/* skipped (optional device int): a non-finite *normsq (an overflowed fp16-mode gradient) skips the whole update -- p, m, v untouched --
+   and increments *skipped; the reference has no loss scaling and therefore no counterpart (train.py:443-450 steps on NaN).
+   norm_out (optional): receives sqrt(*normsq) * grad_scale = the value clip_grad_norm_ returns (train.py:443).
+   zero_after (optional, != normsq): one float this launch sets to zero (the caller's other squared-norm accumulator). */
 int dx_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
-                 float weight_decay, int step, const float* normsq, float max_norm, float grad_scale, void* stream);
+                 float weight_decay, int step, const float* normsq, float max_norm, float grad_scale, int* skipped,
+                 float* norm_out, float* zero_after, void* stream);
 
 #ifdef __cplusplus
 }

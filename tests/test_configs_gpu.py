@@ -24,12 +24,15 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 ITERATION = 4000
 
-# ---- stated bf16-operand tolerances (throughput mode; fp32 accumulate, bf16 MFMA operands, bf16-stored 1024-wide tensors) ----
-BF16_MEL_L1 = 1.5e-2          # valid-frame mean |mel - mel_oracle| (mel values are O(1..5); 12 stacked blocks)
-BF16_LOSS_REL = 1e-2          # each of the 7 loss terms, relative
-BF16_GRAD_COS = 0.995         # per-parameter cosine similarity with the oracle gradient (tensors with >= 64 elements)
-BF16_GRAD_REL = 0.10          # per-parameter max-norm relative error  max|g - g_ref| / max|g_ref|
-BF16_GRAD_COS_SMALL = 0.97    # tensors below 64 elements (post_multipliers, range projection bias ...)
+# ---- stated 16-bit-operand tolerances (throughput modes; fp32 accumulate, 16-bit MFMA operands, 16-bit-stored 1024-wide tensors) ----
+# Each bar is <= 1.5 x the value measured on MI355X at C2 (profiles/r02_parity_c2_*.json).  None of them is the 1e-4
+# north-star bar: that one is met by the f32 mode only (test_c2_f32_* below); bench.py prints this next to the throughput.
+BARS = {
+    #            valid-frame mean |mel - oracle|; each loss term, relative; per-parameter max-norm relative gradient error;
+    #            cosine with the oracle gradient (>= 64 elements); cosine for tensors below 64 elements
+    'bf16': {'mel_l1': 8.4e-3, 'loss_rel': 6e-3, 'grad_rel': 0.075, 'grad_cos': 0.9972, 'grad_cos_small': 0.97},    # measured 5.6e-3, 3.8e-3, 5.0e-2, 0.9981
+    'fp16': {'mel_l1': 1.2e-3, 'loss_rel': 9e-4, 'grad_rel': 0.041, 'grad_cos': 0.9995, 'grad_cos_small': 0.97},    # measured 8.0e-4, 5.7e-4, 2.7e-2, 0.9997
+}
 
 
 def valid_mel_l1(mel, ref, out_lens):
@@ -157,26 +160,28 @@ def test_c2_bf16_forward_loss_gradients_vs_oracle(pkg, c2, precision):
     small = {k: v for k, v in rows.items() if v[2] < 64}
     worst_rel = max(rows.items(), key=lambda kv: kv[1][0])
     worst_cos = min(big.items(), key=lambda kv: kv[1][1])
-    _dump(f'parity_c2_{precision}.json', {'mel_l1': l1, 'loss_terms_rel': term_err, 'loss_total': [got['total'], ref['total']],
+    bars = BARS[precision]
+    _dump(f'parity_c2_{precision}.json', {'mel_l1': l1, 'bar_mel_l1': bars['mel_l1'], 'bars': bars, 'loss_terms_rel': term_err, 'loss_total': [got['total'], ref['total']],
                                   'worst_grad_rel': [worst_rel[0], worst_rel[1][0]], 'worst_grad_cos': [worst_cos[0], worst_cos[1][1]],
                                   'grads': {k: [v[0], v[1]] for k, v in rows.items()}})
     print(f'C2 {precision}: valid mel L1 {l1:.3e}; loss total {got["total"]:.5f} vs {ref["total"]:.5f}; worst term rel {max(term_err.values()):.3e}; '
           f'worst grad rel {worst_rel[1][0]:.3e} ({worst_rel[0]}); worst grad cos {worst_cos[1][1]:.5f} ({worst_cos[0]})')
-    assert l1 < BF16_MEL_L1, l1
-    assert abs(got['total'] - ref['total']) <= BF16_LOSS_REL * abs(ref['total'])
+    assert l1 < bars['mel_l1'], l1
+    assert abs(got['total'] - ref['total']) <= bars['loss_rel'] * abs(ref['total'])
     for k, e in term_err.items():
-        assert e <= BF16_LOSS_REL, (k, e)
+        assert e <= bars['loss_rel'], (k, e)
     for k, (rel, cos, _) in big.items():
-        assert cos >= BF16_GRAD_COS and rel <= BF16_GRAD_REL, (k, rel, cos)
+        assert cos >= bars['grad_cos'] and rel <= bars['grad_rel'], (k, rel, cos)
     for k, (rel, cos, _) in small.items():
-        assert cos >= BF16_GRAD_COS_SMALL, (k, rel, cos)
+        assert cos >= bars['grad_cos_small'], (k, rel, cos)
 
 
-@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
-def test_c2_trainer_gradient_path_equals_plain_autograd(pkg, c2, precision):
+@pytest.mark.parametrize('precision,cuts', [('bf16', 3), ('fp16', 3), ('bf16', 0)])
+def test_c2_trainer_gradient_path_equals_plain_autograd(pkg, c2, precision, cuts):
     """The gradients the TRAINER computes on the C2 batch - kernels accumulating straight into the all-reduce buckets (sink), the FFT
     blocks' weight gradients queued and launched eight layers at a time, the step arena, loss scaling in fp16 - against plain autograd
-    (.grad tensors, one launch per weight gradient) of the same model, same mode, dropout off: same kernels, other summation orders."""
+    (.grad tensors, one launch per weight gradient) of the same model, same mode, dropout off: same kernels, other summation orders.
+    ``cuts`` = 3: the four-phase backward of an N > 1 step (three cuts, four exchange groups); 0: the single phase of one rank."""
     from ubisoft_laforge_daft_exprt_amd.trainer import Trainer
     hp, batch, _ = c2
     hp = hp.without_dropout() if hasattr(hp, 'without_dropout') else hp
@@ -189,13 +194,26 @@ def test_c2_trainer_gradient_path_equals_plain_autograd(pkg, c2, precision):
         crit.load_pitch_predictor(helpers.golden_pitch_predictor_state_dict())
     finally:
         pkg.set_precision('f32')
-    t = Trainer(model, crit, hp, use_graphs=False)
+    t = Trainer(model, crit, hp, use_graphs=False, cuts=cuts)
     assert model.runtime.sink and model.runtime.defer_wgrad
+    assert sorted(set(t.reducer.bucket_group)) == list(range(cuts + 1))
+    plan = t.exchange_plan()
+    assert plan['total_bytes'] == 4 * sum(p.numel() for p in model.parameters())
+    if cuts == 3:
+        assert plan['exposed_fraction'] <= 0.25, plan       # what is launched after the last backward kernel
     t.iteration = ITERATION
     dev_batch = tuple(x.to(DEV) if torch.is_tensor(x) else x for x in batch)
     parsed, _ = t._parse([dev_batch])
-    _, _, phase_b = t._phases(parsed, ITERATION, t.reducer.launch_group)      # the eager form of train_step, without the optimiser
-    phase_b()
+    launched = []
+
+    def launch(gid):
+        launched.append(gid)
+        t.reducer.launch_group(gid)
+    _, _, rest = t._phases(parsed, ITERATION, launch)      # the eager form of train_step, without the optimiser
+    assert len(rest) == cuts
+    for run in rest:
+        run()
+    assert launched == list(range(cuts + 1))
     t.reducer.finish()
     torch.cuda.synchronize()
     assert not model.runtime.wgrad_queue
@@ -212,10 +230,10 @@ def test_c2_trainer_gradient_path_equals_plain_autograd(pkg, c2, precision):
     t.reducer.remove()
 
 
-def test_c2_phase_b_gradients_with_bucket_traffic_on_another_queue(pkg, c2):
-    """What an N > 1 step does on the device, on one GPU: while phase B (accent-encoder backward, its kernels adding into group 1's
-    buckets with memory-side float atomics) runs on the compute stream, another queue reads and rewrites group 0's buckets in place, as
-    the all-reduce does.  Every gradient must equal the serial step's (summation order only), group 0's included."""
+def test_c2_later_phases_with_bucket_traffic_on_another_queue(pkg, c2):
+    """What an N > 1 step does on the device, on one GPU: while phases B, C, D (accent-encoder backward, its kernels adding into the
+    later groups' buckets with memory-side float atomics) run on the compute stream, another queue reads and rewrites the buckets of the
+    groups already finished in place, as their all-reduces do.  Every gradient must equal the serial step's (summation order only)."""
     from ubisoft_laforge_daft_exprt_amd.trainer import Trainer
     hp, batch, _ = c2
     hp = hp.without_dropout() if hasattr(hp, 'without_dropout') else hp
@@ -227,24 +245,27 @@ def test_c2_phase_b_gradients_with_bucket_traffic_on_another_queue(pkg, c2):
         crit.load_pitch_predictor(helpers.golden_pitch_predictor_state_dict())
     finally:
         pkg.set_precision('f32')
-    t = Trainer(model, crit, hp, use_graphs=False)
+    t = Trainer(model, crit, hp, use_graphs=False, cuts=3)
     t.iteration = ITERATION
     red = t.reducer
-    assert sorted(set(red.bucket_group)) == [0, 1] and all(o % 1024 == 0 for o in red.bucket_offset)
+    assert sorted(set(red.bucket_group)) == [0, 1, 2, 3] and all(o % 1024 == 0 for o in red.bucket_offset)
     dev_batch = tuple(x.to(DEV) if torch.is_tensor(x) else x for x in batch)
     parsed, _ = t._parse([dev_batch])
     side = torch.cuda.Stream()
 
     def step(traffic):
-        _, _, phase_b = t._phases(parsed, ITERATION, red.launch_group)
-        if traffic:
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(12):                               # ~1 ms of in-place traffic over 40 MB, the length of phase B
-                    for bi, flat in enumerate(red.flat):
-                        if red.bucket_group[bi] == 0:
-                            flat.mul_(1.0)
-        phase_b()
+        def launch(gid):
+            red.launch_group(gid)
+            if traffic and gid < 3:                               # "all-reduce" of the finished group beside the next phase
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(8):                            # several passes of in-place traffic, the length of the next phase
+                        for bi, flat in enumerate(red.flat):
+                            if red.bucket_group[bi] == gid:
+                                flat.mul_(1.0)
+        _, _, rest = t._phases(parsed, ITERATION, launch)
+        for run in rest:
+            run()
         torch.cuda.current_stream().wait_stream(side)
         red.finish()
         torch.cuda.synchronize()
@@ -257,7 +278,7 @@ def test_c2_phase_b_gradients_with_bucket_traffic_on_another_queue(pkg, c2):
         # fp32 atomics land in another order from run to run; a value that then becomes a 16-bit GEMM operand can round the other way
         # (seen: 3.8e-4 on one parameter, once).  A lost update of one workgroup's contribution would be 1e-2.
         assert worst[0] < 2e-3, worst
-    print(f'C2 bf16: phase B beside bucket traffic on another queue vs serial, worst relative difference {worst[0]:.2e} at {worst[1]}')
+    print(f'C2 bf16: later phases beside bucket traffic on another queue vs serial, worst relative difference {worst[0]:.2e} at {worst[1]}')
     red.remove()
 
 
@@ -271,7 +292,7 @@ def _c4(device):
     return tuple(mv(t) for t in inputs), {k: mv(v) for k, v in prosody.items()}, mv(spk), mv(accent)
 
 
-@pytest.mark.parametrize('precision,tol', [('f32', 2e-5), ('bf16', BF16_MEL_L1), ('fp16', BF16_MEL_L1)])
+@pytest.mark.parametrize('precision,tol', [('f32', 2e-5), ('bf16', 6e-3), ('fp16', 1e-3)])      # measured 7.3e-7, 3.9e-3, 6.6e-4
 def test_c4_inference_b256_vs_oracle(pkg, precision, tol):
     from oracle import daft_exprt_oracle as oracle
     from ubisoft_laforge_daft_exprt_amd.inference import GraphedSynthesizer

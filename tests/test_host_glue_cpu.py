@@ -20,3 +20,24 @@ def test_split_film_matches_per_block_slicing():
         assert torch.equal(parts[i], ref[:, i, :])
     assert torch.equal(film.grad, ref.grad)
     assert torch.count_nonzero(film.grad[:, 2]) == 0
+
+
+def test_exchange_groups_leave_at_most_a_quarter_of_the_gradient_bytes_exposed():
+    """trainer.group_of over the reference's 184 parameters (reversed registration order, as ddp.GradientReducer packs them): every
+    group is ONE contiguous run (so groups never share a bucket and need no tiny extra all-reduce), the groups appear in phase order,
+    and the group launched after the last backward kernel holds <= 25 % of the 57.5 MB (VERDICT r2, next #3)."""
+    from tests import helpers
+    from ubisoft_laforge_daft_exprt_amd.trainer import group_of
+    shapes = helpers.manifest()['model']
+    names = list(shapes)[::-1]
+    numel = lambda k: int(__import__('math').prod(shapes[k])) if shapes[k] else 1
+    total = sum(numel(k) for k in names)
+    for levels in (0, 1, 2, 3):
+        gids = [group_of(k, levels) for k in names]
+        runs = [g for i, g in enumerate(gids) if i == 0 or g != gids[i - 1]]
+        assert runs == list(range(levels + 1)), (levels, runs)
+        last = sum(numel(k) for k, g in zip(names, gids) if g == levels)
+        if levels == 3:
+            assert last / total <= 0.25 and last / total < 0.03, last / total     # prenet layer 0 + prosody embeddings: ~1 MB
+        if levels == 2:
+            assert 0.25 < last / total < 0.28                                   # the whole prenet: why there is a third cut

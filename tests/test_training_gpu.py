@@ -168,7 +168,8 @@ def test_optimizer_state_round_trips_with_torch_adam_layout(oracle_run):
 
 
 def test_graph_replay_matches_eager_two_phase_step():
-    """The captured two-graph step (trainer.Trainer(use_graphs=True)) against the same step issued eagerly: identical loss and
+    """The captured step (trainer.Trainer(use_graphs=True), the four-phase / four-graph form of an N > 1 step) against the one-phase
+    step issued eagerly: identical loss and
     parameter trajectory at dropout p = 0, over several batches of two alternating padded shapes (so both graph sets are replayed
     after other work has run); with dropout on, replays of one shape draw different masks (device-side seed offset)."""
     import ubisoft_laforge_daft_exprt_amd as pkg
@@ -194,7 +195,7 @@ def test_graph_replay_matches_eager_two_phase_step():
             crit.load_pitch_predictor(helpers.golden_pitch_predictor_state_dict())
         finally:
             pkg.set_precision('f32')
-        t = Trainer(model, crit, hp, use_graphs=mode)
+        t = Trainer(model, crit, hp, use_graphs=mode, cuts=3 if mode else 0)
         losses, l1 = [], []
         for b in batches:
             loss, terms, _ = t.train_step([b])
@@ -202,7 +203,7 @@ def test_graph_replay_matches_eager_two_phase_step():
             l1.append(terms[0]['mel_spec_l1_loss'])
         runs[mode] = (losses, l1, {k: p.detach().clone() for k, p in model.named_parameters()})
         if mode:
-            assert len(t.graphs) == 2 and all(g.hits == 4 for g in t.graphs.values())
+            assert len(t.graphs) == 2 and all(g.hits == 4 and len(g.graphs) == 4 for g in t.graphs.values())
     (le, l1e, pe), (lg, l1g, pg) = runs[False], runs[True]
     print('eager', le, 'graph', lg)
     assert abs(le[0] - lg[0]) <= 1e-6 * abs(le[0])                        # the first step runs the same kernels on the same weights
@@ -229,3 +230,156 @@ def test_graph_replay_matches_eager_two_phase_step():
     t = Trainer(model, crit, hp_d.clone(initial_learning_rate=0.0, max_learning_rate=0.0), use_graphs=True)   # lr 0: weights stay put
     vals = [float(t.train_step([batches[0]])[0]) for _ in range(3)]
     assert len(t.graphs) == 1 and len({round(v, 6) for v in vals}) == 3, vals
+
+
+def _fresh(hp, precision='bf16'):
+    import ubisoft_laforge_daft_exprt_amd as pkg
+    pkg.set_precision(precision)
+    try:
+        model = pkg.DaftExprt(hp).to(DEV)
+        model.load_state_dict(helpers.golden_state_dict(), strict=True)
+        crit = pkg.DaftExprtLoss(DEV, hp)
+        crit.load_pitch_predictor(helpers.golden_pitch_predictor_state_dict())
+    finally:
+        pkg.set_precision('f32')
+    return model, crit
+
+
+def _speaker_stats(seed, speakers=(0, 1, 2)):
+    g = torch.Generator().manual_seed(seed)
+    return {s: {'pitch': {'mean': 4.0 + 0.3 * s + 0.1 * seed, 'std': 0.5 + 0.1 * s}, 'energy': {'mean': 1.0 + 0.2 * s + 0.05 * seed, 'std': 0.7 + 0.1 * s},
+                'spk_emb': torch.randn(192, generator=g)} for s in speakers}
+
+
+def test_conditioner_refresh_reaches_captured_graphs():
+    """a captured training graph holds the conditioner's table POINTERS.  ``BatchConditioner.update`` (the reference's
+    ``refresh_stats``) must therefore write in place; a refresh that has to grow the tables drops the graphs.  Graph-replayed steps
+    before and after both kinds of refresh equal the eager trainer's."""
+    from ubisoft_laforge_daft_exprt_amd.conditioning import BatchConditioner
+    from ubisoft_laforge_daft_exprt_amd.synth import synthetic_batch
+    from ubisoft_laforge_daft_exprt_amd.trainer import Trainer
+    hp = helpers.golden_hparams(initial_learning_rate=0.0, max_learning_rate=0.0)      # lr 0: both trainers keep the golden weights
+    batch = synthetic_batch(4, (12, 24), seed=77, n_speakers=3)
+    losses = {}
+    for mode in (False, True):
+        model, crit = _fresh(hp)
+        cond = BatchConditioner(_speaker_stats(1), DEV, capacity=4)
+        t = Trainer(model, crit, hp, conditioner=cond, use_graphs=mode)
+        out = [float(t.train_step([batch])[0])]
+        ptrs = (cond.table.data_ptr(), cond.valid.data_ptr(), cond.emb.data_ptr())
+        cond.update(_speaker_stats(2))                                      # in-place refresh: same pointers, the graph stays
+        assert ptrs == (cond.table.data_ptr(), cond.valid.data_ptr(), cond.emb.data_ptr())
+        out.append(float(t.train_step([batch])[0]))
+        if mode:
+            assert len(t.graphs) == 1 and next(iter(t.graphs.values())).hits == 2
+        cond.update(_speaker_stats(3, speakers=(0, 1, 2, 9)))                # speaker 9 does not fit 4 rows: re-allocation
+        assert cond.n >= 10
+        out.append(float(t.train_step([batch])[0]))
+        if mode:
+            assert next(iter(t.graphs.values())).hits == 1                   # captured anew against the new tables
+        losses[mode] = out
+    print('conditioner refresh: eager', losses[False], 'graphs', losses[True])
+    assert len({round(v, 5) for v in losses[False]}) == 3                    # the three statistics really differ
+    for a, b in zip(losses[False], losses[True]):
+        assert abs(a - b) <= 2e-5 * abs(a), losses
+
+
+def test_load_checkpoint_into_captured_trainer_repacks_weights():
+    """graph replays read the MFMA weight packs through frozen pointers; ``load_checkpoint`` into a trainer whose
+    graphs are already captured must be followed by a re-pack before the next replay.  The next-step loss after loading equals a
+    fresh trainer's that loaded the same checkpoint."""
+    from ubisoft_laforge_daft_exprt_amd.synth import synthetic_batch
+    from ubisoft_laforge_daft_exprt_amd.trainer import Trainer
+    hp = helpers.golden_hparams(initial_learning_rate=2e-3, max_learning_rate=2e-3, warmup_steps=10, grad_clip_thresh=5.0)
+    batch = synthetic_batch(4, (12, 24), seed=78, n_speakers=3)
+    model, crit = _fresh(hp)
+    t = Trainer(model, crit, hp)
+    first = float(t.train_step([batch])[0])
+    ck0 = None
+    for _ in range(3):
+        t.train_step([batch])
+    moved = float(t.train_step([batch])[0])
+    assert abs(moved - first) > 1e-3 * abs(first)                             # five updates at lr 2e-3 moved the loss
+    # a checkpoint of the GOLDEN weights, loaded into the trainer whose graphs (and packs) belong to the moved weights
+    model0, crit0 = _fresh(hp)
+    t0 = Trainer(model0, crit0, hp)
+    ck0 = t0.checkpoint()
+    t.load_checkpoint(ck0)
+    got = float(t.train_step([batch])[0])
+    want = float(t0.train_step([batch])[0])
+    assert len(t.graphs) == 1
+    assert abs(got - want) <= 2e-5 * abs(want), (got, want, first, moved)
+    # the checkpoint records the learning rate the saved iteration USED (train.py:451-455), not the next one
+    from ubisoft_laforge_daft_exprt_amd.optim import update_learning_rate
+    ck = t0.checkpoint()
+    assert ck['iteration'] == 1 and ck['learning_rate'] == update_learning_rate(hp, 1)
+
+
+def test_fp16_overflow_skips_the_update_on_a_non_finite_norm():
+    """ADVICE r2 (low) / VERDICT r2 weak #13: one inf in a gradient makes the squared norm non-finite; the fused Adam must leave
+    parameters and both moments untouched and count the skipped step, and the next finite step must update normally."""
+    from ubisoft_laforge_daft_exprt_amd.synth import synthetic_batch
+    from ubisoft_laforge_daft_exprt_amd.trainer import Trainer
+    hp = helpers.golden_hparams(initial_learning_rate=1e-3, max_learning_rate=1e-3, grad_clip_thresh=5.0)
+    batch = synthetic_batch(3, (10, 16), seed=79, n_speakers=3)
+    model, crit = _fresh(hp, 'fp16')
+    t = Trainer(model, crit, hp, use_graphs=False)
+    t.train_step([batch])
+    opt = t.optimizer
+    p0, m0, v0 = opt.p_all.clone(), opt.m_all.clone(), opt.v_all.clone()
+    assert t.skipped_steps() == 0
+    t.reducer.zero_grad()
+    t.reducer.flat_all.normal_()
+    t.reducer.flat_all[12345] = float('inf')
+    norm = opt.step(lr=1e-3, grad_scale=1.0 / t.loss_scale)
+    assert not torch.isfinite(norm).item()
+    assert torch.equal(opt.p_all, p0) and torch.equal(opt.m_all, m0) and torch.equal(opt.v_all, v0)
+    assert t.skipped_steps() == 1
+    t.reducer.flat_all[12345] = float('nan')                                 # NaN as well
+    opt.step(lr=1e-3, grad_scale=1.0 / t.loss_scale)
+    assert torch.equal(opt.p_all, p0) and t.skipped_steps() == 2
+    loss, _, norm = t.train_step([batch])                                    # and a finite step still updates
+    assert torch.isfinite(norm).item() and torch.isfinite(loss).item() and not torch.equal(opt.p_all, p0)
+    assert t.skipped_steps() == 2
+
+
+def test_validate_matches_oracle_eval_mode():
+    """``Trainer.validate`` = train.py:163-209: eval mode, no gradients, iteration 0 in the loss, mean over batches; the captured form
+    (one graph per padded shape) equals the eager form and the CPU oracle."""
+    from oracle import daft_exprt_oracle as oracle
+    from ubisoft_laforge_daft_exprt_amd.synth import synthetic_batch
+    from ubisoft_laforge_daft_exprt_amd.trainer import Trainer
+    import ubisoft_laforge_daft_exprt_amd as pkg
+    hp_drop = pkg.HyperParams(n_speakers=helpers.manifest()['n_speakers'])   # dropout ON in the hparams: eval mode must switch it off
+    batches = [synthetic_batch(4, (12, 24), seed=500 + i, n_speakers=3, zero_dur_frac=0.1) for i in range(3)]
+    batches.append(batches[0])                                                # a shape seen before: replayed, not captured again
+    sd, pp = helpers.golden_state_dict(), helpers.golden_pitch_predictor_state_dict()
+    ref_tot, ref_terms = 0.0, None
+    with torch.no_grad():
+        for b in batches:
+            inputs = tuple(b[i] for i in range(11)) + (b[13],)
+            targets = (b[1], b[3], b[4], b[8], b[9], b[10], b[6], b[7])
+            out = oracle.forward(sd, inputs, hp_drop, training=False)
+            loss, terms = oracle.loss(out, targets, 0, hp_drop, pp)
+            ref_tot += float(loss) / len(batches)
+            ref_terms = {k: (0.0 if ref_terms is None else ref_terms[k]) + float(v) / len(batches) for k, v in terms.items()}
+    results = {}
+    for mode in (False, True):
+        model, crit = _fresh(hp_drop, 'f32')
+        t = Trainer(model, crit, hp_drop, use_graphs=mode)
+        results[mode] = t.validate(batches)
+        assert model.training                                                 # back in train mode
+        assert all(p.grad is None or float(p.grad.abs().sum()) == 0.0 for p in model.parameters())
+        if mode:
+            assert len(t.val_graphs) == len({(tuple(b[0].shape), tuple(b[8].shape)) for b in batches})
+    (le, te), (lg, tg) = results[False], results[True]
+    print(f'validate: oracle {ref_tot:.6f}, eager {le:.6f}, graphs {lg:.6f}')
+    assert abs(le - lg) <= 1e-6 * abs(le)
+    assert abs(le - ref_tot) <= 1e-4 * abs(ref_tot)
+    assert te['speaker_loss'] == 0.0                                          # iteration 0: adversarial weight 0
+    for k, v in ref_terms.items():
+        assert abs(tg[k] - v) <= 1e-4 * max(abs(v), 1e-3), (k, tg[k], v)
+    # keep_outputs: (targets, outputs) per batch, as the reference hands them to its logger
+    model, crit = _fresh(hp_drop, 'f32')
+    l3, _, kept = Trainer(model, crit, hp_drop).validate(batches[:2], keep_outputs=True)
+    assert len(kept) == 2 and kept[0][1][3][0].shape[1] == 80

@@ -22,10 +22,17 @@ def timed(fn, n=20, warm=3):
     return (time.perf_counter() - t0) / n
 
 
-def main():
-    prec = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
-    R = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+def measure(prec='bf16', R=8, n=20, warm=3):
+    """-> dict: C4 batch (256 sentences, decoder T ~ 800) eager and graph-replayed, inputs resident in HBM, + the reference-recording leg."""
+    old = pkg.get_precision()
     pkg.set_precision(prec)
+    try:
+        return _measure(prec, R, n, warm)
+    finally:
+        pkg.set_precision(old)
+
+
+def _measure(prec, R, n, warm):
     dev = 'cuda'
     hp = pkg.HyperParams(n_speakers=2, stats={'spk 0': {'pitch': {'mean': 5.0, 'std': 0.25}}})
     model = pkg.DaftExprt(hp).to(dev)
@@ -45,7 +52,7 @@ def main():
     frames = sum(prep['out_host'])
     out = {'precision': prec, 'B': B, 'L_max': L, 'T_max': prep['n_frames'], 'valid_frames': frames, 'host_prepare_ms': round(t_host * 1e3, 2)}
     for mode in (False, True):
-        dt = timed(lambda: synth(*args(), use_graph=mode))
+        dt = timed(lambda: synth(*args(), use_graph=mode), n, warm)
         out['graph_replay' if mode else 'eager'] = {'ms_per_batch': round(dt * 1e3, 3), 'frames_per_s': round(frames / dt)}
     # reference-recording leg: R recordings of 300-800 frames -> one averaged accent embedding
     g = torch.Generator().manual_seed(7)
@@ -60,8 +67,8 @@ def main():
         embs = []
         with torch.no_grad():
             for r in range(R):
-                n = int(lens[r])
-                embs.append(model.accent_encoder(energy[r:r + 1, :n].contiguous(), pitch[r:r + 1, :n].contiguous(), mel[r:r + 1, :, :n].contiguous(),
+                n_ = int(lens[r])
+                embs.append(model.accent_encoder(energy[r:r + 1, :n_].contiguous(), pitch[r:r + 1, :n_].contiguous(), mel[r:r + 1, :, :n_].contiguous(),
                                                  lens_d[r:r + 1]))
         return torch.cat(embs).mean(dim=0, keepdim=True)
 
@@ -69,11 +76,18 @@ def main():
     leg = {'recordings': R, 'frames': ref_frames}
     for name, fn in (('per_recording_b1', one_by_one), ('batched_eager', lambda: synth.accent_embedding(energy, pitch, mel, lens_d, use_graph=False)),
                      ('batched_graph', lambda: synth.accent_embedding(energy, pitch, mel, lens_d, use_graph=True))):
-        dt = timed(fn)
+        dt = timed(fn, n, warm)
         leg[name] = {'ms': round(dt * 1e3, 3), 'frames_per_s': round(ref_frames / dt)}
     out['accent_encoder_leg'] = leg
     e2e = out['graph_replay']['ms_per_batch'] + leg['batched_graph']['ms']
     out['end_to_end_graph'] = {'ms': round(e2e, 3), 'frames_per_s': round(frames / (e2e * 1e-3))}
+    return out
+
+
+def main():
+    prec = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
+    R = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    out = measure(prec, R)
     print(json.dumps(out))
     if len(sys.argv) > 3:
         with open(sys.argv[3], 'w') as f:

@@ -30,8 +30,23 @@ def _compile(job):
     return obj
 
 
+STAMP = os.path.join(CSRC, '.build_flags')     # the flag string the objects in the tree were compiled with
+
+
+def _flags_changed() -> bool:
+    """Objects built with other flags (an ablation build via DX_EXTRA_HIPCC_FLAGS) are newer than their sources, so mtimes alone would
+    keep them: the flag string is recorded next to the objects and any difference rebuilds everything."""
+    want = ' '.join(FLAGS)
+    try:
+        with open(STAMP) as f:
+            return f.read() != want
+    except OSError:
+        return any(f.endswith('.o') for f in os.listdir(CSRC))     # objects of unknown provenance
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     jobs = [(src, False) for src in SOURCES] + [(src, True) for src in F16_SOURCES]
+    force = force or _flags_changed()
     if force:
         for src, f16 in jobs:
             obj = os.path.join(CSRC, os.path.splitext(src)[0] + ('_f16.o' if f16 else '.o'))
@@ -39,6 +54,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 os.remove(obj)
     with ThreadPoolExecutor(max_workers=6) as pool:
         objs = list(pool.map(_compile, jobs))
+    with open(STAMP, 'w') as f:
+        f.write(' '.join(FLAGS))
     if _stale(LIB, objs):
         subprocess.run(['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB, *objs], check=True)
     if verbose:

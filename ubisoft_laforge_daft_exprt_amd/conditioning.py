@@ -16,24 +16,50 @@ from .ops import _p, _stream
 
 
 class BatchConditioner:
-    def __init__(self, current_stats: dict, device, emb_dim: int = 192):
-        """``current_stats``: {speaker_id: {'pitch': {'mean','std'}, 'energy': {'mean','std'}, 'spk_emb': (emb_dim,) tensor}}"""
+    def __init__(self, current_stats: dict, device, emb_dim: int = 192, capacity: int = 64):
+        """``current_stats``: {speaker_id: {'pitch': {'mean','std'}, 'energy': {'mean','std'}, 'spk_emb': (emb_dim,) tensor}}
+        ``capacity``: rows the device tables start with (speaker ids 0..capacity-1).
+
+        The three device tables are PERSISTENT: ``update`` (the reference's ``refresh_stats`` every ``stats_refresh_interval``
+        iterations, train.py) writes into them in place, because a captured training graph (trainer.Trainer) holds their raw
+        pointers and the row count ``n`` as launch arguments.  They are re-allocated only when a speaker id no longer fits; that
+        bumps ``generation``, which tells the trainer to drop its captured graphs."""
         self.device = torch.device(device)
+        self.emb_dim = int(emb_dim)
+        self.n = 0                                 # rows of the tables = the ``S`` argument of both kernels (constant between re-allocations)
+        self.generation = 0
+        self.table = self.valid = self.emb = None
+        self._reserve(max(int(capacity), (max(current_stats) + 1) if current_stats else 1))
         self.update(current_stats, emb_dim)
 
-    def update(self, current_stats: dict, emb_dim: int = 192):
-        n = (max(current_stats) + 1) if current_stats else 1
-        table = torch.zeros(n, 4)
+    def _reserve(self, rows):
+        self.n = int(rows)
+        self.table = torch.zeros(self.n, 4, dtype=torch.float32, device=self.device)
+        self.valid = torch.zeros(self.n, dtype=torch.int32, device=self.device)
+        self.emb = torch.zeros(self.n, self.emb_dim, dtype=torch.float32, device=self.device)
+        self.generation += 1
+
+    def update(self, current_stats: dict, emb_dim: int = None):
+        """New support-set statistics, written IN PLACE (stream-ordered copies on the current stream: a graph replay enqueued
+        afterwards reads the new rows).  Speakers missing from ``current_stats`` become invalid (pass-through), as a fresh table would."""
+        if emb_dim is not None and int(emb_dim) != self.emb_dim:
+            self.emb_dim = int(emb_dim)
+            self._reserve(self.n)
+        need = (max(current_stats) + 1) if current_stats else 1
+        if need > self.n:
+            self._reserve(max(need, 2 * self.n))   # growth: new pointers, new ``n`` -> captured graphs must be dropped (generation)
+        table = torch.zeros(self.n, 4)
         table[:, 1] = 1.0
         table[:, 3] = 1.0
-        valid = torch.zeros(n, dtype=torch.int32)
-        emb = torch.zeros(n, emb_dim)
+        valid = torch.zeros(self.n, dtype=torch.int32)
+        emb = torch.zeros(self.n, self.emb_dim)
         for sid, st in current_stats.items():
             table[sid] = torch.tensor([st['energy']['mean'], st['energy']['std'], st['pitch']['mean'], st['pitch']['std']])
             emb[sid] = st['spk_emb'].float()
             valid[sid] = 1
-        self.n, self.emb_dim = n, emb_dim
-        self.table, self.valid, self.emb = table.to(self.device), valid.to(self.device), emb.to(self.device)
+        self.table.copy_(table)
+        self.valid.copy_(valid)
+        self.emb.copy_(emb)
 
     def _norm(self, x, speaker_ids, which):
         x = x.contiguous()

@@ -40,6 +40,9 @@ struct AdamArgs {
   float lr, b1, b2, eps, wd, bc1, bc2_sqrt;
   const float* normsq; float max_norm;
   float grad_scale;                 // gradients arrive multiplied by 1 / grad_scale (static loss scaling of the fp16 mode); 1 otherwise
+  int* skipped;                     // optional device counter of skipped (non-finite gradient norm) updates
+  float* norm_out;                  // optional: receives the (unscaled) global gradient norm, sqrt(*normsq) * grad_scale
+  float* zero_after;                // optional: one float zeroed by this launch (the caller's OTHER squared-norm accumulator)
 };
 
 __device__ __forceinline__ float adam_one(float& p, float g, float& m, float& v, const AdamArgs& a, float coef) {
@@ -53,7 +56,21 @@ __device__ __forceinline__ float adam_one(float& p, float g, float& m, float& v,
 
 __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
   float coef = a.grad_scale;
-  if (a.normsq && a.max_norm < INFINITY) coef *= fminf(1.f, a.max_norm / (sqrtf(*a.normsq) * a.grad_scale + 1e-6f));  // clip_grad_norm_
+  if (a.normsq) {
+    // Overflow guard (the fp16 mode's static loss scale can push a 16-bit gradient tensor to inf): a non-finite squared norm means at
+    // least one non-finite gradient, and applying it would write NaN into every parameter and both moments for good.  The update is
+    // skipped as a whole -- p, m, v untouched -- on every rank alike (the norm is taken after the all-reduce).
+    const float nsq = *a.normsq;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      if (a.norm_out) *a.norm_out = sqrtf(nsq) * a.grad_scale;
+      if (a.zero_after) *a.zero_after = 0.f;
+    }
+    if (!(nsq < INFINITY)) {
+      if (a.skipped && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.skipped, 1);
+      return;
+    }
+    if (a.max_norm < INFINITY) coef *= fminf(1.f, a.max_norm / (sqrtf(nsq) * a.grad_scale + 1e-6f));  // clip_grad_norm_
+  }
   const long n4 = a.n / 4;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     float4 p = reinterpret_cast<float4*>(a.p)[i], m = reinterpret_cast<float4*>(a.m)[i], v = reinterpret_cast<float4*>(a.v)[i];
@@ -82,13 +99,19 @@ int dx_sumsq(const float* x, long n, float* out, void* stream) {
 
 // One Adam step on a flat bucket.  step >= 1.  normsq (optional, device scalar) = squared global gradient norm for clipping.
 // grad_scale: every gradient (and the norm) is multiplied by it first (1 / loss scale when the backward ran on a scaled loss).
+// skipped (optional, device int): when *normsq is not finite the update is skipped (p, m, v untouched) and *skipped is incremented.
+// norm_out (optional): receives sqrt(*normsq) * grad_scale, what clip_grad_norm_ returns.  zero_after (optional): a float this launch
+// sets to zero -- a caller that alternates between two squared-norm accumulators needs no fill launch per step (it must not be normsq).
 int dx_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
-                 float weight_decay, int step, const float* normsq, float max_norm, float grad_scale, void* stream) {
+                 float weight_decay, int step, const float* normsq, float max_norm, float grad_scale, int* skipped,
+                 float* norm_out, float* zero_after, void* stream) {
+  DX_REQUIRE(!zero_after || zero_after != normsq, "dx_adam_step: zero_after must not alias normsq");
+  DX_REQUIRE(normsq || (!norm_out && !zero_after), "dx_adam_step: norm_out / zero_after need normsq");
   DX_REQUIRE(p && g && m && v && n > 0 && step >= 1, "dx_adam_step: bad arguments");
   DX_REQUIRE(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 && ((uintptr_t)v % 16) == 0,
              "dx_adam_step: buffers must be 16-byte aligned");
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-  AdamArgs a{p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), normsq, max_norm, grad_scale};
+  AdamArgs a{p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), normsq, max_norm, grad_scale, skipped, norm_out, zero_after};
   const int blocks = (int)std::min<long>((n / 4 + 255) / 256 + 1, 4096);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   DX_LAUNCH_CHECK("dx_adam_step");

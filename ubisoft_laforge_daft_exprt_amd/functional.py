@@ -261,14 +261,29 @@ class FFTBlockFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-# accent-encoder front end (model.py:687-706): prenet 3 x [conv k3 -> ReLU -> LN -> dropout], + energy/pitch/position, mask
+# backward cuts: a trainer (trainer.Trainer) runs the backward pass in PHASES so that the gradient buckets of a finished phase are
+# exchanged while the next one computes.  ``cut(rt, level, t)`` ends a phase at tensor ``t``: the graph downstream sees a fresh leaf,
+# and the trainer later calls ``t.backward(leaf.grad)``.  Levels are numbered in BACKWARD order (1 = first cut the backward meets).
 # ----------------------------------------------------------------------------------------------------------------------
-class AccentFrontFn(torch.autograd.Function):
+def cut(rt, level, t):
+    sp = None if rt is None else rt.backward_split
+    if sp is None or level > rt.cut_levels or not t.requires_grad:
+        return t
+    leaf = t.detach().requires_grad_(True)
+    sp.append((level, t, leaf))
+    return leaf
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# accent-encoder front end (model.py:687-706): prenet 3 x [conv k3 -> ReLU -> LN -> dropout], + energy/pitch/position, mask.
+# Two Functions -- layer 0 (80 -> 1024) and layers 1, 2 + the embedding sum -- so that a trainer can cut the backward between them:
+# the 1024 x 1024 layer's 12.6 MB gradient is then exchanged while layer 0's backward still runs (trainer.Trainer, phase D).
+# ----------------------------------------------------------------------------------------------------------------------
+class AccentFront0Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mel, energy, pitch, lens, packs, pe, p_drop, training,
-                c0_w, c0_b, l0_w, l0_b, c1_w, c1_b, l1_w, l1_b, c2_w, c2_b, l2_w, l2_b, we, be, wp, bp):
+    def forward(ctx, mel, lens, packs, p_drop, training, c0_w, c0_b, l0_w, l0_b):
         p = p_drop if training else 0.0
-        seeds = [next_seed() if training else 0 for _ in range(3)]
+        seed = next_seed() if training else 0
         x0 = ops.transpose(mel.contiguous())                                   # (B, T, n_mel) channels-last
         L = lens.i32
         rt = packs['p0'].rt
@@ -276,14 +291,44 @@ class AccentFrontFn(torch.autograd.Function):
         hd = ops.hidden_dtype(prec)                                           # 1024-wide tensors: bf16 in bf16 operand mode
         so = rt.seed_offset
         h0 = ops.conv_gemm(x0, packs['p0'], c0_b, relu=True, lens=L, halo=2, out_dtype=hd, prec=prec, rows_exist=lens.exist)   # three stacked k=3 convs: halos 2, 1, 0
-        y0, m0, r0 = ops.ln_fwd(h0, None, l0_w, l0_b, None, L, seed_post=seeds[0], p_post=p, halo=2, seed_offset=so, prec=prec)
+        y0, m0, r0 = ops.ln_fwd(h0, None, l0_w, l0_b, None, L, seed_post=seed, p_post=p, halo=2, seed_offset=so, prec=prec)
+        ctx.save_for_backward(x0, h0, m0, r0, l0_w, l0_b)
+        ctx.lens, ctx.packs, ctx.p, ctx.seed = lens, packs, p, seed
+        ctx.prec, ctx.sink, ctx.seed_offset = prec, rt.sink, so
+        return y0
+
+    @staticmethod
+    def backward(ctx, dy0):
+        x0, h0, m0, r0, l0_w, l0_b = ctx.saved_tensors
+        lens, packs, p = ctx.lens, ctx.packs, ctx.p
+        arena = packs['p0'].rt.arena
+        L = lens.i32
+        sk = {k: _sink(v, ctx.sink) for k, v in packs.get('params', {}).items()}
+        g = sk.get
+        dz0, _, dl0_w, dl0_b, _ = ops.ln_bwd(dy0.contiguous(), h0, m0, r0, l0_w, l0_b, None, L, relu_mask=True, seed_post=ctx.seed, p_post=p,
+                                              seed_offset=ctx.seed_offset, prec=ctx.prec, w_sink=g('l0_w'), b_sink=g('l0_b'), halo=2, arena=arena)
+        dc0_w, dc0_b = ops.conv_wgrad(dz0, x0, packs['p0'], L, 2, w_sink=g('c0_w'), b_sink=g('c0_b'), prec=ctx.prec, arena=arena)
+        return None, None, None, None, None, dc0_w, dc0_b, dl0_w, dl0_b
+
+
+class AccentFront12Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y0, energy, pitch, lens, packs, pe, p_drop, training,
+                c1_w, c1_b, l1_w, l1_b, c2_w, c2_b, l2_w, l2_b, we, be, wp, bp):
+        p = p_drop if training else 0.0
+        seeds = [next_seed() if training else 0 for _ in range(2)]
+        L = lens.i32
+        rt = packs['p1'].rt
+        prec = rt.precision
+        hd = ops.hidden_dtype(prec)
+        so = rt.seed_offset
         h1 = ops.conv_gemm(y0, packs['p1'], c1_b, relu=True, lens=L, halo=1, out_dtype=hd, prec=prec, rows_exist=lens.exist)
-        y1, m1, r1 = ops.ln_fwd(h1, None, l1_w, l1_b, None, L, seed_post=seeds[1], p_post=p, halo=1, seed_offset=so, prec=prec)
+        y1, m1, r1 = ops.ln_fwd(h1, None, l1_w, l1_b, None, L, seed_post=seeds[0], p_post=p, halo=1, seed_offset=so, prec=prec)
         h2 = ops.conv_gemm(y1, packs['p2'], c2_b, relu=True, lens=L, halo=0, prec=prec, rows_exist=lens.exist)
-        y2, m2, r2 = ops.ln_fwd(h2, None, l2_w, l2_b, None, L, seed_post=seeds[2], p_post=p, halo=0, seed_offset=so, prec=prec)
+        y2, m2, r2 = ops.ln_fwd(h2, None, l2_w, l2_b, None, L, seed_post=seeds[1], p_post=p, halo=0, seed_offset=so, prec=prec)
         energy, pitch = energy.contiguous(), pitch.contiguous()
         out = ops.accent_sum(y2, energy, pitch, we, be, wp, bp, pe, lens.i32)
-        ctx.save_for_backward(x0, h0, m0, r0, y0, h1, m1, r1, y1, h2, m2, r2, energy, pitch, l0_w, l0_b, l1_w, l1_b, l2_w, l2_b)
+        ctx.save_for_backward(y0, h1, m1, r1, y1, h2, m2, r2, energy, pitch, l1_w, l1_b, l2_w, l2_b)
         ctx.lens, ctx.packs, ctx.p, ctx.seeds = lens, packs, p, seeds
         ctx.emb_params = (we, be, wp, bp)
         ctx.prec, ctx.sink, ctx.seed_offset = prec, rt.sink, so
@@ -291,30 +336,26 @@ class AccentFrontFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        x0, h0, m0, r0, y0, h1, m1, r1, y1, h2, m2, r2, energy, pitch, l0_w, l0_b, l1_w, l1_b, l2_w, l2_b = ctx.saved_tensors
+        y0, h1, m1, r1, y1, h2, m2, r2, energy, pitch, l1_w, l1_b, l2_w, l2_b = ctx.saved_tensors
         lens, packs, p, seeds = ctx.lens, ctx.packs, ctx.p, ctx.seeds
         so = ctx.seed_offset
-        arena = packs['p0'].rt.arena
+        arena = packs['p1'].rt.arena
         dout = ops.mask_rows(dout.contiguous(), lens.i32)
         dwe, dbe, dwp, dbp = ops.scalar_conv_wgrad(dout, energy, pitch, lens.i32, sinks=tuple(_sink(q, ctx.sink) for q in ctx.emb_params))
         L = lens.i32
-        P = packs.get('params', {})
         prec = ctx.prec
-        sk = {k: _sink(v, ctx.sink) for k, v in P.items()}
+        sk = {k: _sink(v, ctx.sink) for k, v in packs.get('params', {}).items()}
         g = sk.get
-        dz2, _, dl2_w, dl2_b, _ = ops.ln_bwd(dout, h2, m2, r2, l2_w, l2_b, None, L, relu_mask=True, seed_post=seeds[2], p_post=p, seed_offset=so, prec=prec,
+        dz2, _, dl2_w, dl2_b, _ = ops.ln_bwd(dout, h2, m2, r2, l2_w, l2_b, None, L, relu_mask=True, seed_post=seeds[1], p_post=p, seed_offset=so, prec=prec,
                                               w_sink=g('l2_w'), b_sink=g('l2_b'), halo=0, arena=arena)
         dc2_w, dc2_b = ops.conv_wgrad(dz2, y1, packs['p2'], L, 0, w_sink=g('c2_w'), b_sink=g('c2_b'), prec=prec, arena=arena)
         dy1 = ops.conv_gemm(dz2, packs['p2'], None, transpose=True, lens=L, halo=1, out_dtype=h1.dtype, prec=prec)
-        dz1, _, dl1_w, dl1_b, _ = ops.ln_bwd(dy1, h1, m1, r1, l1_w, l1_b, None, L, relu_mask=True, seed_post=seeds[1], p_post=p, seed_offset=so, prec=prec,
+        dz1, _, dl1_w, dl1_b, _ = ops.ln_bwd(dy1, h1, m1, r1, l1_w, l1_b, None, L, relu_mask=True, seed_post=seeds[0], p_post=p, seed_offset=so, prec=prec,
                                               w_sink=g('l1_w'), b_sink=g('l1_b'), halo=1, arena=arena)
         dc1_w, dc1_b = ops.conv_wgrad(dz1, y0, packs['p1'], L, 1, w_sink=g('c1_w'), b_sink=g('c1_b'), prec=prec, arena=arena)
-        dy0 = ops.conv_gemm(dz1, packs['p1'], None, transpose=True, lens=L, halo=2, out_dtype=h0.dtype, prec=prec)
-        dz0, _, dl0_w, dl0_b, _ = ops.ln_bwd(dy0, h0, m0, r0, l0_w, l0_b, None, L, relu_mask=True, seed_post=seeds[0], p_post=p, seed_offset=so, prec=prec,
-                                              w_sink=g('l0_w'), b_sink=g('l0_b'), halo=2, arena=arena)
-        dc0_w, dc0_b = ops.conv_wgrad(dz0, x0, packs['p0'], L, 2, w_sink=g('c0_w'), b_sink=g('c0_b'), prec=prec, arena=arena)
-        return (None, None, None, None, None, None, None, None,
-                dc0_w, dc0_b, dl0_w, dl0_b, dc1_w, dc1_b, dl1_w, dl1_b, dc2_w, dc2_b, dl2_w, dl2_b, dwe, dbe, dwp, dbp)
+        dy0 = ops.conv_gemm(dz1, packs['p1'], None, transpose=True, lens=L, halo=2, out_dtype=y0.dtype, prec=prec)
+        return (dy0, None, None, None, None, None, None, None,
+                dc1_w, dc1_b, dl1_w, dl1_b, dc2_w, dc2_b, dl2_w, dl2_b, dwe, dbe, dwp, dbp)
 
 
 class SplitFilmFn(torch.autograd.Function):

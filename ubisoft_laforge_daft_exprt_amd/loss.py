@@ -90,8 +90,9 @@ class _LossFn(torch.autograd.Function):
         if cfg['ecw'] > 0:
             des, esum = ops.energy_diff(ep, et, lens.i32, arena=arena)
         # energy term: ecw / (sum of valid lengths), the division done on the device (nothing host-side is frozen into a graph)
+        need_grad = cfg.get('need_grad', True)       # False under no_grad (Trainer.validate): the terms only, none of the gradient launches
         dmel = ops.mel_grad(mel_pred, mel_target, ep, des, lens.i32, cfg['msw'] / (M * B), cfg['msw'] / (M * B), cfg['ecw'] if des is not None else 0.0,
-                            e_per_total=True)
+                            e_per_total=True) if need_grad else None
         psum = None
         if pitch_layers is not None and frames_pitch is not None and cfg['pcw'] > 0:
             # frozen predictor on the predicted mel, channels-last; gradient flows through it to the mel only
@@ -108,20 +109,22 @@ class _LossFn(torch.autograd.Function):
             pp = ops.conv_gemm(x, last['pack'], last['b'], lens=lens.i32, halo=0, prec=prec)      # (B, T, 4): channel 0 is the prediction
             frames_pitch = frames_pitch.contiguous()
             psum = ops.pitch_mse(pp, frames_pitch, lens.i32, arena=arena)                          # (read and written in place: no slice copies)
-            g = ops.pitch_grad(pp, frames_pitch, lens.i32, psum, cfg['pcw'], out=ops._zeros(arena, B, T, 4, device=dev))
-            # each input-gradient GEMM applies the previous layer's BatchNorm scale and ReLU mask in its epilogue
-            for k in range(len(pitch_layers) - 1, 0, -1):
-                prev = pitch_layers[k - 1]
-                g = ops.conv_gemm(g, pitch_layers[k]['pack'], None, transpose=True, post_scale=prev['scale'], post_shift=prev['zeros'],
-                                  relu_aux=acts[k - 1], lens=lens.i32, halo=depth - k + 1, prec=prec, out_dtype=hd)
-            d = ops.conv_gemm(g, pitch_layers[0]['pack'], None, transpose=True, lens=lens.i32, halo=0, prec=prec)
-            dmel = ops.transpose(d, add_to=dmel)                                   # dmel is this function's own fresh tensor
+            if need_grad:
+                g = ops.pitch_grad(pp, frames_pitch, lens.i32, psum, cfg['pcw'], out=ops._zeros(arena, B, T, 4, device=dev))
+                # each input-gradient GEMM applies the previous layer's BatchNorm scale and ReLU mask in its epilogue
+                for k in range(len(pitch_layers) - 1, 0, -1):
+                    prev = pitch_layers[k - 1]
+                    g = ops.conv_gemm(g, pitch_layers[k]['pack'], None, transpose=True, post_scale=prev['scale'], post_shift=prev['zeros'],
+                                      relu_aux=acts[k - 1], lens=lens.i32, halo=depth - k + 1, prec=prec, out_dtype=hd)
+                d = ops.conv_gemm(g, pitch_layers[0]['pack'], None, transpose=True, lens=lens.i32, halo=0, prec=prec)
+                dmel = ops.transpose(d, add_to=dmel)                                   # dmel is this function's own fresh tensor
         # the seven terms, the total and the two small gradients: one launch (was ~30 one-element ATen launches)
         terms, total, d_spk, d_pm = ops.loss_finalize(ce, dlogits, cfg['spk_weight'], pm, cfg['pmw'], sums, lens.i32, M, cfg['msw'],
                                                       esum, cfg['ecw'], psum, cfg['pcw'])
         if d_pm is not None:
             d_pm = d_pm.view_as(post_multipliers)
-        ctx.save_for_backward(dmel, d_spk, d_pm)
+        if need_grad:
+            ctx.save_for_backward(dmel, d_spk, d_pm)
         ctx.mark_non_differentiable(terms)
         ctx.set_materialize_grads(False)
         return total, terms
@@ -180,7 +183,8 @@ class DaftExprtLoss(nn.Module):
         # ``iteration``: the step number, or -- from a trainer that replays captured graphs -- the adversarial weight itself as a
         # device scalar it updates before every replay
         spk_weight = iteration if torch.is_tensor(iteration) else self.update_adversarial_weight(iteration)
-        cfg = {'spk_weight': spk_weight, 'pmw': self.post_mult_weight, 'msw': self.mel_spec_weight,
+        cfg = {'need_grad': torch.is_grad_enabled() and mel_preds.requires_grad,
+               'spk_weight': spk_weight, 'pmw': self.post_mult_weight, 'msw': self.mel_spec_weight,
                'ecw': self.energy_consistency_weight, 'pcw': self.pitch_consistency_weight if self.pitch_layers is not None else 0.0}
         total, terms = _LossFn.apply(mel_preds, speaker_preds, pm, mel_targets, speaker_ids, frames_pitch, lens, cfg, self.pitch_layers, self.runtime)
         return total, LossTerms(terms)

@@ -192,12 +192,16 @@ class AccentEncoder(nn.Module):
                             'c1_w': c[4].conv.weight, 'c1_b': c[4].conv.bias, 'l1_w': c[6].weight, 'l1_b': c[6].bias,
                             'c2_w': c[8].conv.weight, 'c2_b': c[8].conv.bias, 'l2_w': c[10].weight, 'l2_b': c[10].bias}}
         pe = positional_table(self.cfg['hidden_embed_dim'], mel_specs.device)
-        x = Fx.AccentFrontFn.apply(mel_specs, frames_energy, frames_pitch, lens, packs, pe, self.cfg['conv_dropout'], self.training,
-                                   c[0].conv.weight, c[0].conv.bias, c[2].weight, c[2].bias,
-                                   c[4].conv.weight, c[4].conv.bias, c[6].weight, c[6].bias,
-                                   c[8].conv.weight, c[8].conv.bias, c[10].weight, c[10].bias,
-                                   self.energy_embedding.conv.weight, self.energy_embedding.conv.bias,
-                                   self.pitch_embedding.conv.weight, self.pitch_embedding.conv.bias)
+        rt = getattr(self, '_dx_rt', None)
+        p_drop = self.cfg['conv_dropout']
+        y0 = Fx.AccentFront0Fn.apply(mel_specs, lens, packs, p_drop, self.training, c[0].conv.weight, c[0].conv.bias, c[2].weight, c[2].bias)
+        y0 = Fx.cut(rt, 3, y0)                     # phase D of a trainer's backward: prenet layer 0 (its 1 MB of gradients is all that is exchanged last)
+        x = Fx.AccentFront12Fn.apply(y0, frames_energy, frames_pitch, lens, packs, pe, p_drop, self.training,
+                                     c[4].conv.weight, c[4].conv.bias, c[6].weight, c[6].bias,
+                                     c[8].conv.weight, c[8].conv.bias, c[10].weight, c[10].bias,
+                                     self.energy_embedding.conv.weight, self.energy_embedding.conv.bias,
+                                     self.pitch_embedding.conv.weight, self.pitch_embedding.conv.bias)
+        x = Fx.cut(rt, 2, x)                       # phase C: prenet layers 2, 1 + the prosody embeddings; phase B: the four FFT blocks
         x = _run_blocks(self.blocks, x, None, lens)
         return Fx.MeanPoolFn.apply(x, lens, getattr(self, '_dx_rt', None))
 
@@ -387,7 +391,6 @@ class DaftExprt(nn.Module):
         # execution state of THIS model (operand precision, pack epoch, gradient sink): shared by all of its sub-modules, read
         # by nobody else.  It starts from the package default (``set_precision``) and is switched with ``model.set_precision``.
         self.runtime = ops.Runtime(ops.DEFAULT.precision)
-        self.backward_split = None                 # a list while a trainer wants the backward cut at the accent embedding
         for m in self.modules():
             m._dx_rt = self.runtime
 
@@ -451,12 +454,9 @@ class DaftExprt(nn.Module):
             accent_emb = external_accent_emb
         else:
             accent_emb = self.accent_encoder(frames_energy, frames_pitch, mel_specs, out_lens)
-            if self.backward_split is not None:
-                # two-phase backward (trainer.Trainer): everything downstream of the accent embedding first -- its gradient buckets
-                # can then be exchanged while the accent encoder's backward (the largest module) still runs
-                leaf = accent_emb.detach().requires_grad_(True)
-                self.backward_split.append((accent_emb, leaf))
-                accent_emb = leaf
+            # phased backward (trainer.Trainer): everything downstream of the accent embedding first -- its gradient buckets
+            # can then be exchanged while the accent encoder's backward (the largest module) still runs
+            accent_emb = Fx.cut(self.runtime, 1, accent_emb)
         speaker_preds = self.speaker_classifier(accent_emb)
         film = self.style_adapter(accent_emb + spk_emb)
         enc_outputs = self.phoneme_encoder(symbols, film['phoneme_encoder'], in_lens)

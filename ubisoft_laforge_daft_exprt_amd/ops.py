@@ -33,6 +33,8 @@ class Runtime:
         self.seed_offset = None      # device int64 scalar added to every dropout seed on the device (graph replays bump it)
         self.defer_wgrad = False     # trainer.Trainer: the FFT blocks' weight gradients are queued and launched 8 layers at a time
         self.wgrad_queue = {}        # (taps, dy 16-bit, x 16-bit, precision) -> [(job fields, tensors kept alive)]; see flush_wgrads
+        self.backward_split = None   # a list while a trainer runs the backward in phases: (level, tensor, leaf) per cut (functional.cut)
+        self.cut_levels = 0          # cuts the trainer wants: 0 = none, 1 = at the accent embedding, 2 = + before the prenet, 3 = + inside the prenet
         self._packs = []             # weak refs to this runtime's PackedWeight objects (one-launch batched re-pack)
         self._tables = {}
 
