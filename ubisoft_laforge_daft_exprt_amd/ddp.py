@@ -28,11 +28,14 @@ import torch.distributed as dist
 
 class GradientReducer:
     def __init__(self, module: torch.nn.Module, bucket_mb: float = 16.0, process_group=None, grad_sink: bool = False,
-                 broadcast_parameters: bool = True, group_of=None):
+                 broadcast_parameters: bool = True, group_of=None, explicit_launch: bool = False):
         """``grad_sink=True``: the HIP backward kernels accumulate straight into the bucket views (the model's ``runtime.sink``);
         requires ``zero_grad()`` of THIS object before every step.
         ``group_of(parameter name) -> int``: parameters of different groups never share a bucket (``bucket_group[i]`` is bucket
-        i's group), so a caller that finishes backward group by group can exchange a group as soon as it is complete."""
+        i's group), so a caller that finishes backward group by group can exchange a group as soon as it is complete.
+        ``explicit_launch=True`` (trainer.Trainer): the caller runs the backward in phases and launches every group itself
+        (``launch_group``); the hooks then only COUNT gradients -- a bucket may fill over several phases and micro-batches -- and
+        ``finish()`` checks that every parameter was counted equally often."""
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -80,6 +83,8 @@ class GradientReducer:
                 self.bucket_of[p] = bi
             self.flat.append(flat)
         self.pending = [len(b) for b in self.buckets]
+        self.explicit = bool(explicit_launch)
+        self.seen = [0] * len(self.buckets)       # explicit mode: gradients counted per bucket since zero_grad()
         self.launched = set()                     # buckets whose exchange has been launched explicitly in this step
         self.works = []
         self.sync = True
@@ -99,6 +104,9 @@ class GradientReducer:
 
     def _on_grad(self, p):
         bi = self.bucket_of[p]
+        if self.explicit:
+            self.seen[bi] += 1
+            return
         self.pending[bi] -= 1
         if self.pending[bi] == 0 and self.world > 1 and self.sync:
             op = self._reduce_op()
@@ -110,11 +118,15 @@ class GradientReducer:
         self.flat_all.zero_()
         self.launched.clear()
         self.pending = [len(b) for b in self.buckets]
+        self.seen = [0] * len(self.buckets)
 
     @contextlib.contextmanager
     def accumulate(self, sync: bool = True):
         """One micro-batch's backward inside a gradient-accumulation step.  ``sync=False``: its gradients are only summed
         into the buckets; ``sync=True`` (the last micro-batch): completed buckets are all-reduced as usual."""
+        if self.explicit:                          # phases of a trainer's backward: nothing to reset, nothing launches by itself
+            yield self
+            return
         self._check_balanced()
         self.pending = [0 if bi in self.launched else len(b) for bi, b in enumerate(self.buckets)]
         self.sync = bool(sync)
@@ -130,7 +142,15 @@ class GradientReducer:
 
     def finish(self):
         """Call after backward: waits for the collectives; gradients are then averaged over ranks."""
-        if any(n != 0 for n in self.pending):
+        if self.explicit:
+            rounds = {n / len(b) for n, b in zip(self.seen, self.buckets)}
+            # (a replayed HIP graph runs no Python hooks: all counts are then zero, and the same sequence was checked when it was captured)
+            if len(rounds) != 1 or min(rounds) != int(min(rounds)) or len(self.launched) != len(self.buckets):
+                raise RuntimeError(f'gradient bookkeeping out of balance after backward: gradients counted per bucket = {self.seen} for buckets of '
+                                   f'{[len(b) for b in self.buckets]} parameters, launched = {sorted(self.launched)} (a parameter received no '
+                                   'gradient, was counted twice, or a group was never launched)')
+            self.seen = [0] * len(self.buckets)
+        elif any(n != 0 for n in self.pending):
             raise RuntimeError(f'gradient bookkeeping out of balance after backward: pending per bucket = {self.pending} '
                                '(a parameter received no gradient, or was counted twice)')
         for work, bi, op in self.works:

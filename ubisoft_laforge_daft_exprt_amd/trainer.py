@@ -82,7 +82,7 @@ class Trainer:
         if not 0 <= self.cut_levels <= 3:
             raise ValueError(f'cuts must be 0..3 or "auto", got {cuts!r}')
         self.reducer = GradientReducer(model, bucket_mb=bucket_mb, process_group=process_group, grad_sink=grad_sink,
-                                       group_of=lambda n: group_of(n, self.cut_levels))
+                                       group_of=lambda n: group_of(n, self.cut_levels), explicit_launch=True)
         self.use_graphs, self.max_graphs = bool(use_graphs), int(max_graphs)
         # the FFT blocks' weight gradients go straight into the buckets (sink) and have no consumer before the exchange, so they are
         # queued during backward and launched 8 layers at a time (ops.flush_wgrads, after every backward phase below)
