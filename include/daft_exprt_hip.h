@@ -144,12 +144,17 @@ int dx_ff_block_bwd(const float* dY2, const float* z2, const float* mean2, const
 int dx_colsum(const void* X, int ldx, float* out, long rows, int C, int x_bf16, void* stream);
 
 /* ---- multi-head attention: model.py:165-186 (nn.MultiheadAttention slow path), called from :255 ------------------- */
+/* order[0..B) = utterance indices sorted by length, longest first (stable): the optional `order` argument of the attention entry
+ * points.  A workgroup's work grows with its utterance's length and workgroups start in blockIdx order: longest first removes the tail
+ * of a launch.  Pure scheduling: results do not depend on it.  (No reference counterpart: get_mask_from_lengths, model.py:14-24, is
+ * the only use the reference makes of the lengths.) */
+int dx_length_order(const int* lens, int* order, int B, void* stream);
 int dx_attention_fwd(const void* qkv, int ld, const int* lens, void* ctx, int ldc, float* lse,
                      int B, int N, int H, int D, uint64_t seed, const uint64_t* seed_offset, float p_drop, int bf16, int qkv_bf16, int ctx_bf16,
-                     void* stream);
+                     const int* order, void* stream);
 int dx_attention_bwd(const void* qkv, int ld, const void* ctx, const void* dctx, int ldc, const float* lse, float* delta,
                      const int* lens, void* dqkv, int ldg, int B, int N, int H, int D, uint64_t seed, const uint64_t* seed_offset, float p_drop, int bf16,
-                     int qkv_bf16, int dqkv_bf16, int ctx_bf16, void* stream);
+                     int qkv_bf16, int dqkv_bf16, int ctx_bf16, const int* order, void* stream);
 /* bf16 = 1: QK^T / PV (and the five backward products) on v_mfma_f32_16x16x32_bf16, softmax and accumulation in fp32;
  * qkv_bf16 / dqkv_bf16 / ctx_bf16 = 1: the in-projection output / its gradient / the attention context are stored as bf16 (ld in
  * elements; ctx and dctx share ldc AND the storage type: ctx_bf16 = 1 means both are 16-bit).  The context is only ever consumed as a 16-bit GEMM operand (out-projection, its weight gradient)

@@ -337,6 +337,33 @@ def _attention_forward_backward(ops, B, N, lens, tol_f, tol_b):
         assert rel_err(dq_c.float(), qkv.grad) < tol_b
 
 
+@pytest.mark.parametrize('precision', ['f32', 'bf16'])
+def test_attention_longest_first_order_changes_nothing(ops, precision):
+    """``dx_length_order`` = stable argsort by length, descending; handing the attention workgroups out in that order is pure
+    scheduling: forward, log-sum-exp and all three gradients are BITWISE the same with and without it, dropout included (the dropout
+    counters are built from the utterance's own index, not from blockIdx)."""
+    lens = [70, 200, 13, 200, 129, 64, 1]
+    B, N, heads = len(lens), 200, 2
+    ln = lens_tensor(lens)
+    order = ops.length_order(ln)
+    want = torch.tensor(sorted(range(B), key=lambda i: (-lens[i], i)), dtype=torch.int32)
+    assert torch.equal(order.cpu(), want)
+    ops.set_precision(precision)
+    try:
+        h = ops.hidden_dtype()
+        qkv = randn(B, N, 384, seed=5).to(h)
+        dctx = (randn(B, N, 128, seed=6) * (torch.arange(N, device=DEV)[None, :] < ln[:, None])[:, :, None].float()).to(h)
+        for seed, p in ((0, 0.0), (77, 0.1)):
+            a, la = ops.attention_fwd(qkv, ln, heads, seed, p, ctx_dtype=h)
+            b, lb = ops.attention_fwd(qkv, ln, heads, seed, p, ctx_dtype=h, order=order)
+            assert torch.equal(a, b) and torch.equal(la, lb)
+            ga = ops.attention_bwd(qkv, a, dctx, la, ln, heads, seed, p, out_dtype=h)
+            gb = ops.attention_bwd(qkv, b, dctx, lb, ln, heads, seed, p, out_dtype=h, order=order)
+            assert torch.equal(ga, gb)
+    finally:
+        ops.set_precision('f32')
+
+
 @pytest.mark.parametrize('precision', ['f32', 'bf16', 'fp16'])
 def test_attention_dropout_mask_consistency(ops, precision):
     ops.set_precision(precision)

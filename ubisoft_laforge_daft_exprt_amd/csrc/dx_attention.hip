@@ -33,6 +33,7 @@ struct AttnArgs {
   int B, N, H, D;
   uint64_t seed; uint32_t thresh; float inv_keep;
   const uint64_t* seed_offset;     // optional device scalar added to `seed` (captured HIP graphs: a new dropout stream per replay)
+  const int* order;                // optional [B]: utterance indices, longest first (dx_length_order): blockIdx.z -> utterance
 };
 
 __device__ __forceinline__ f32x4 mma4(const float4& a, const float4& b, f32x4 c) {
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a_) {
   if (a.seed_offset) a.seed += *a.seed_offset;
   __shared__ __attribute__((aligned(16))) float Ks[64 * TLD];
   __shared__ __attribute__((aligned(16))) float Vs[64 * TLD];
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int len = a.lens[b];
@@ -188,6 +189,7 @@ struct AttnBwdArgs {
   const float* ctx;                       // [B*N][ldc]: the bf16 dQ kernel computes delta itself (and stores it for dK/dV)
   float* delta_out;
   const uint64_t* seed_offset;
+  const int* order;                       // as in AttnArgs
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
   if (a.seed_offset) a.seed += *a.seed_offset;
   __shared__ __attribute__((aligned(16))) float Ks[64 * TLD];
   __shared__ __attribute__((aligned(16))) float Vs[64 * TLD];
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int len = a.lens[b];
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
   __shared__ __attribute__((aligned(16))) float Qs[64 * TLD];
   __shared__ __attribute__((aligned(16))) float Gs[64 * TLD];
   __shared__ float lse_s[64], delta_s[64];
-  const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
+  const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int len = a.lens[b];
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a_
   if (a.seed_offset) a.seed += *a.seed_offset;
   __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * 128];
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int len = a.lens[b];
@@ -619,7 +621,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
   if (a.seed_offset) a.seed += *a.seed_offset;
   __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * 128];
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int len = a.lens[b];
@@ -721,14 +723,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
   }
 }
 
+// three waves per SIMD where the prefetch registers hold 16-bit tiles (the model's configuration: 158 registers); the fp32-stored
+// variants (kernel tests) would spill at that cap and stay at two
 template <typename QT, typename OT, typename CT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwdArgs a_) {
+__global__ __launch_bounds__(256, (sizeof(QT) == 2 && sizeof(CT) == 2) ? 3 : 2) void attn_bwd_dkv_bf16_kernel(const AttnBwdArgs a_) {
   AttnBwdArgs a = a_;
   if (a.seed_offset) a.seed += *a.seed_offset;
   __shared__ __attribute__((aligned(16))) unsigned char Qs[64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char Gs[64 * 128];
   __shared__ float lse_s[64], delta_s[64];
-  const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
+  const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int len = a.lens[b];
@@ -782,64 +786,64 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwd
       lse_r = (tid < 64 && qn < a.N) ? a.lse[(size_t)bh * a.N + qn] : 0.f;
       delta_r = (tid < 64 && qn < a.N) ? a.delta[(size_t)bh * a.N + qn] : 0.f;
     }
-    f32x4 pd[4], ds[4];
     const bool tail_q = qbase + 64 > len, tail_k = k0 + 64 > len;
     // Dropout words: one 64-bit draw covers 4 consecutive keys of a query row.  Here a lane owns ONE key and 16 query rows, and
     // the four lanes of a quad (keys 4m .. 4m+3) need the same 16 words: each lane draws 4 of them (rows g*4 + its quad index)
     // and the quad shares them by DPP instead of every lane drawing all 16 (the draws were ~40 % of this kernel's VALU time).
-    uint32_t wlo[4], whi[4];
-    if (a.thresh) {
+    // The tile is walked in two HALVES of 32 queries: scores / probabilities of a half (2 x 16 queries), then that half's eight
+    // dV^T / dK^T MFMAs.  Only one half's P and dS registers are live at a time (16 instead of 32) and each draw is made where it is
+    // used: 186 -> <= 168 registers, i.e. three waves per SIMD instead of two for a kernel that is bound by its dependent
+    // chain (stage, barrier, multiply), not by instruction issue.  The accumulation order per element is unchanged (bitwise).
 #pragma unroll
-      for (int qt = 0; qt < 4; ++qt) {
-        const uint64_t w = dx_rand64(a.seed, drop_index(bh, a.N, qbase + qt * 16 + g * 4 + (r & 3), krow) >> 2);
-        wlo[qt] = (uint32_t)w; whi[qt] = (uint32_t)(w >> 32);
+    for (int half = 0; half < 2; ++half) {
+      f32x4 pd[2], ds[2];
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        const int qt = half * 2 + q2;
+        uint32_t wlo = 0, whi = 0;
+        if (a.thresh) {
+          const uint64_t w = dx_rand64(a.seed, drop_index(bh, a.N, qbase + qt * 16 + g * 4 + (r & 3), krow) >> 2);
+          wlo = (uint32_t)w; whi = (uint32_t)(w >> 32);
+        }
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          s = DX_MFMA_BF16(row_frag(Qs, qt * 16 + r, ks, g), kf[ks], s);
+          dp = DX_MFMA_BF16(row_frag(Gs, qt * 16 + r, ks, g), vf[ks], dp);
+        }
+        float p[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) p[e] = __builtin_amdgcn_exp2f(s[e] - lse_s[qt * 16 + g * 4 + e]);
+        if (tail_k || tail_q) {                             // wave-uniform: padding keys / queries exist only in the last tiles
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (!key_valid || qbase + qt * 16 + g * 4 + e >= len) p[e] = 0.f;
+        }
+        float pk[4] = {p[0], p[1], p[2], p[3]}, u[4], nd[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { nd[e] = -delta_s[qt * 16 + g * 4 + e]; u[e] = dp[e] + nd[e]; }   // subtract BEFORE the asm select (hazard rule)
+        if (a.thresh) {
+          const uint32_t lo0 = __builtin_amdgcn_mov_dpp(wlo, 0x00, 0xF, 0xF, true), hi0 = __builtin_amdgcn_mov_dpp(whi, 0x00, 0xF, 0xF, true);
+          const uint32_t lo1 = __builtin_amdgcn_mov_dpp(wlo, 0x55, 0xF, 0xF, true), hi1 = __builtin_amdgcn_mov_dpp(whi, 0x55, 0xF, 0xF, true);
+          const uint32_t lo2 = __builtin_amdgcn_mov_dpp(wlo, 0xAA, 0xF, 0xF, true), hi2 = __builtin_amdgcn_mov_dpp(whi, 0xAA, 0xF, 0xF, true);
+          const uint32_t lo3 = __builtin_amdgcn_mov_dpp(wlo, 0xFF, 0xF, 0xF, true), hi3 = __builtin_amdgcn_mov_dpp(whi, 0xFF, 0xF, 0xF, true);
+          const uint32_t lo[4] = {lo0, lo1, lo2, lo3}, hi[4] = {hi0, hi1, hi2, hi3};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)       // one byte-permute isolates this key's field; one compare drives both selects; 1/(1-p) rides on V and dV
+            dx_keep2(__builtin_amdgcn_perm(hi[e], lo[e], fsel), thresh_v, pk[e], u[e], nd[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          pd[q2][e] = pk[e];
+          ds[q2][e] = p[e] * u[e];                                          // x QSCALE: applied once to dK at the end
+        }
       }
-    }
+      const bf16x8 pp = pack_pair(pd[0], pd[1]), dd = pack_pair(ds[0], ds[1]);
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
-      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        s = DX_MFMA_BF16(row_frag(Qs, qt * 16 + r, ks, g), kf[ks], s);
-        dp = DX_MFMA_BF16(row_frag(Gs, qt * 16 + r, ks, g), vf[ks], dp);
+      for (int dt = 0; dt < 4; ++dt) {
+        dv[dt] = DX_MFMA_BF16(tr_pair(Gs, half * 32 + g * 4, half * 32 + 16 + g * 4, dt * 16, lane), pp, dv[dt]);
+        dk[dt] = DX_MFMA_BF16(tr_pair(Qs, half * 32 + g * 4, half * 32 + 16 + g * 4, dt * 16, lane), dd, dk[dt]);
       }
-      float p[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) p[e] = __builtin_amdgcn_exp2f(s[e] - lse_s[qt * 16 + g * 4 + e]);
-      if (tail_k || tail_q) {                             // wave-uniform: padding keys / queries exist only in the last tiles
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (!key_valid || qbase + qt * 16 + g * 4 + e >= len) p[e] = 0.f;
-      }
-      float pk[4] = {p[0], p[1], p[2], p[3]}, u[4], nd[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { nd[e] = -delta_s[qt * 16 + g * 4 + e]; u[e] = dp[e] + nd[e]; }   // subtract BEFORE the asm select (hazard rule)
-      if (a.thresh) {
-        const uint32_t lo0 = __builtin_amdgcn_mov_dpp(wlo[qt], 0x00, 0xF, 0xF, true), hi0 = __builtin_amdgcn_mov_dpp(whi[qt], 0x00, 0xF, 0xF, true);
-        const uint32_t lo1 = __builtin_amdgcn_mov_dpp(wlo[qt], 0x55, 0xF, 0xF, true), hi1 = __builtin_amdgcn_mov_dpp(whi[qt], 0x55, 0xF, 0xF, true);
-        const uint32_t lo2 = __builtin_amdgcn_mov_dpp(wlo[qt], 0xAA, 0xF, 0xF, true), hi2 = __builtin_amdgcn_mov_dpp(whi[qt], 0xAA, 0xF, 0xF, true);
-        const uint32_t lo3 = __builtin_amdgcn_mov_dpp(wlo[qt], 0xFF, 0xF, 0xF, true), hi3 = __builtin_amdgcn_mov_dpp(whi[qt], 0xFF, 0xF, 0xF, true);
-        const uint32_t lo[4] = {lo0, lo1, lo2, lo3}, hi[4] = {hi0, hi1, hi2, hi3};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)       // one byte-permute isolates this key's field; one compare drives both selects; 1/(1-p) rides on V and dV
-          dx_keep2(__builtin_amdgcn_perm(hi[e], lo[e], fsel), thresh_v, pk[e], u[e], nd[e]);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        pd[qt][e] = pk[e];
-        ds[qt][e] = p[e] * u[e];                                          // x QSCALE: applied once to dK at the end
-      }
-    }
-    const bf16x8 p01 = pack_pair(pd[0], pd[1]), p23 = pack_pair(pd[2], pd[3]);
-    const bf16x8 d01 = pack_pair(ds[0], ds[1]), d23 = pack_pair(ds[2], ds[3]);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      f32x4 accv = dv[dt], acck = dk[dt];
-      accv = DX_MFMA_BF16(tr_pair(Gs, 0 + g * 4, 16 + g * 4, dt * 16, lane), p01, accv);
-      accv = DX_MFMA_BF16(tr_pair(Gs, 32 + g * 4, 48 + g * 4, dt * 16, lane), p23, accv);
-      acck = DX_MFMA_BF16(tr_pair(Qs, 0 + g * 4, 16 + g * 4, dt * 16, lane), d01, acck);
-      acck = DX_MFMA_BF16(tr_pair(Qs, 32 + g * 4, 48 + g * 4, dt * 16, lane), d23, acck);
-      dv[dt] = accv; dk[dt] = acck;
     }
   }
   if (krow < a.N) {
@@ -855,6 +859,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_bf16_kernel(const AttnBwd
 #undef DX_TILE_LOAD
 #undef DX_TILE_STORE
 
+// order[rank] = b, rank = number of utterances that are longer than b (ties: lower index first): the dispatcher hands out workgroups in
+// blockIdx order, so with blockIdx.z -> order[blockIdx.z] the longest utterances' workgroups start first.
+__global__ __launch_bounds__(1024) void length_order_kernel(const int* __restrict__ lens, int* __restrict__ order, int B) {
+  __shared__ int ls[1024];
+  const int t = threadIdx.x;
+  if (t < B) ls[t] = lens[t];
+  __syncthreads();
+  if (t >= B) return;
+  const int mine = ls[t];
+  int rank = 0;
+  for (int j = 0; j < B; ++j) rank += (ls[j] > mine) || (ls[j] == mine && j < t);
+  order[rank] = t;
+}
+
 int check_common(const char* who, const void* qkv, int ld, int B, int N, int H, int D) {
   DX_REQUIRE(qkv != nullptr, "%s: null pointer", who);
   DX_REQUIRE(B > 0 && N > 0 && H > 0 && D == H * HD, "%s: head dim must be 64 (D=%d, H=%d)", who, D, H);
@@ -867,9 +885,20 @@ int check_common(const char* who, const void* qkv, int ld, int B, int N, int H, 
 
 extern "C" {
 
+// order[0..B) = the utterance indices sorted by length, longest first (stable).  Attention work per workgroup grows with the
+// utterance's length (a 64-query workgroup walks every key tile of its utterance); workgroups are dispatched in blockIdx order, so
+// handing the longest utterances out FIRST keeps a 14-tile workgroup from starting in the last round of a launch and setting its
+// duration alone (C2: a third of the launch time was that tail).
+int dx_length_order(const int* lens, int* order, int B, void* stream) {
+  DX_REQUIRE(lens && order && B > 0 && B <= 1024, "dx_length_order: bad arguments (B <= 1024)");
+  hipLaunchKernelGGL(length_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, lens, order, B);
+  DX_LAUNCH_CHECK("dx_length_order");
+  return DX_OK;
+}
+
 int dx_attention_fwd(const void* qkvv, int ld, const int* lens, void* ctxv, int ldc, float* lse,
                      int B, int N, int H, int D, uint64_t seed, const uint64_t* seed_offset, float p_drop, int bf16, int qkv_bf16, int ctx_bf16,
-                     void* stream) {
+                     const int* order, void* stream) {
   float* ctx = (float*)ctxv;
   const float* qkv = (const float*)qkvv;
   if (int rc = check_common("dx_attention_fwd", qkv, ld, B, N, H, D)) return rc;
@@ -877,7 +906,7 @@ int dx_attention_fwd(const void* qkvv, int ld, const int* lens, void* ctxv, int 
   DX_REQUIRE(lens && ctx && lse && ldc >= D && (ldc % 4) == 0 && ((uintptr_t)ctx % 16) == 0, "dx_attention_fwd: bad output arguments");
   DX_REQUIRE(!ctx_bf16 || (bf16 && (ldc % 8) == 0), "dx_attention_fwd: a 16-bit context needs the 16-bit operand mode and ldc %% 8 == 0");
   DX_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "dx_attention_fwd: dropout p out of range");
-  AttnArgs a{qkv, ld, lens, ctx, ldc, lse, B, N, H, D, seed, (uint32_t)lrintf(p_drop * 65536.f), 1.f / (1.f - p_drop), seed_offset};
+  AttnArgs a{qkv, ld, lens, ctx, ldc, lse, B, N, H, D, seed, (uint32_t)lrintf(p_drop * 65536.f), 1.f / (1.f - p_drop), seed_offset, order};
   hipStream_t s = (hipStream_t)stream;
   dx_prof_begin(DX_PROF_ATTN_FWD, s);
   const dim3 grid(dx_cdiv(N, 64), H, B);
@@ -894,7 +923,7 @@ int dx_attention_fwd(const void* qkvv, int ld, const int* lens, void* ctxv, int 
 // dqkv (all three thirds, every row) from dctx; `delta` is scratch [B][H][N]
 int dx_attention_bwd(const void* qkvv, int ld, const void* ctxv, const void* dctxv, int ldc, const float* lse, float* delta,
                      const int* lens, void* dqkvv, int ldg, int B, int N, int H, int D, uint64_t seed, const uint64_t* seed_offset, float p_drop, int bf16,
-                     int qkv_bf16, int dqkv_bf16, int ctx_bf16, void* stream) {
+                     int qkv_bf16, int dqkv_bf16, int ctx_bf16, const int* order, void* stream) {
   const float* qkv = (const float*)qkvv; float* dqkv = (float*)dqkvv; const float* ctx = (const float*)ctxv; const float* dctx = (const float*)dctxv;
   DX_REQUIRE(!ctx_bf16 || (bf16 && (ldc % 8) == 0), "dx_attention_bwd: a 16-bit context needs the 16-bit operand mode and ldc %% 8 == 0");
   if (int rc = check_common("dx_attention_bwd", qkv, ld, B, N, H, D)) return rc;
@@ -907,7 +936,7 @@ int dx_attention_bwd(const void* qkvv, int ld, const void* ctxv, const void* dct
   const long items = (long)B * N * H;
   if (!bf16)                                       // the bf16 dQ kernel computes delta on the fly and leaves it for dK/dV
     hipLaunchKernelGGL(attn_delta_kernel, dim3((int)std::min<long>((items + 3) / 4, 8192)), dim3(256), 0, s, dctx, ctx, ldc, delta, B, N, H);
-  AttnBwdArgs a{qkv, ld, dctx, ldc, lse, delta, lens, dqkv, ldg, B, N, H, D, seed, (uint32_t)lrintf(p_drop * 65536.f), 1.f / (1.f - p_drop), ctx, delta, seed_offset};
+  AttnBwdArgs a{qkv, ld, dctx, ldc, lse, delta, lens, dqkv, ldg, B, N, H, D, seed, (uint32_t)lrintf(p_drop * 65536.f), 1.f / (1.f - p_drop), ctx, delta, seed_offset, order};
   dx_prof_begin(DX_PROF_ATTN_BWD, s);
   if (bf16) {
     const dim3 grid(dx_cdiv(N, 64), H, B);

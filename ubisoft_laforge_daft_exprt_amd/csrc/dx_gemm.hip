@@ -49,6 +49,7 @@ struct ConvGemmArgs {
   // buffers have N rows per batch row.  NULL = every row has N rows (the reference's padded grid).  Lets one allocation (and one
   // captured graph) serve batches whose logical padded length is smaller than N, and lets a batch row behave as if it were alone.
   const int* rows_exist;
+  int xcd_swizzle;  // conv_dk, several output-channel blocks per token tile: workgroups are renumbered so that a token tile's blocks run together on one XCD
 };
 
 template <typename T> struct Mma;
@@ -665,7 +666,26 @@ __global__ __launch_bounds__(512) void conv_dk_kernel(const ConvGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tiles_n = (a.N + TOK - 1) / TOK;
-  const int co0 = blockIdx.y * TILE;
+  // Workgroup -> (token tile, output-channel block).  Workgroups are dispatched in linear order (x fastest) and dealt to the 8 XCDs
+  // round-robin.  With the plain (tile, block) grid all tiles of block 0 run first, then all of block 1 ...: every activation tile is
+  // fetched once per block, a round of workgroups (~70 MB of activations) apart, i.e. from HBM each time (PMC: 3.2x the algorithmic
+  // bytes for the 1024 -> 1024 layers).  Renumbered: XCD x owns the token tiles t = 8 i + x, and on that XCD the workgroups of a
+  // tile's blocks are CONSECUTIVE, in groups of at most four blocks (4 x 786 KB of weights stay L2-resident; all eight would not fit
+  // the 4 MB next to the activations): the tile is read from HBM once per group and served to the other blocks from the XCD's L2.
+  int tile_id = blockIdx.x, co_blk = blockIdx.y;
+  if (a.xcd_swizzle) {
+    const int nco = gridDim.y, tpx = gridDim.x >> 3;                  // (the host pads gridDim.x to a multiple of 8)
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = lin & 7, j = lin >> 3;
+    const int cg = nco < 4 ? nco : 4;
+    const int per_group = tpx * cg;
+    const int grp = j / per_group, rem = j - grp * per_group;
+    const int t = rem / cg;
+    tile_id = t * 8 + xcd;
+    co_blk = grp * cg + (rem - t * cg);
+    if (tile_id >= a.B * tiles_n) return;                              // padding of the grid
+  }
+  const int co0 = co_blk * TILE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // scalar: everything per-wave below stays in SGPRs
   const int kg = wave >> 2, wq = wave & 3;          // waves w and w+4 share a SIMD: one of each K group
@@ -694,7 +714,7 @@ __global__ __launch_bounds__(512) void conv_dk_kernel(const ConvGemmArgs a) {
     }
     __syncthreads();
     const int nlive = pre_s[a.B];
-    int w = blockIdx.x, lo = 0, hi = a.B;             // largest row lo with key(lo) <= w, key = live (dead) tiles before the row
+    int w = tile_id, lo = 0, hi = a.B;                // largest row lo with key(lo) <= w, key = live (dead) tiles before the row
     live = w < nlive;
     if (!live) w -= nlive;
     while (hi - lo > 1) {
@@ -706,8 +726,8 @@ __global__ __launch_bounds__(512) void conv_dk_kernel(const ConvGemmArgs a) {
     const int live_b = pre_s[b + 1] - pre_s[b];
     n0 = (live ? w - pre_s[b] : live_b + (w - (b * tiles_n - pre_s[b]))) * TOK;
   } else {
-    b = blockIdx.x / tiles_n;
-    n0 = (blockIdx.x - b * tiles_n) * TOK;
+    b = tile_id / tiles_n;
+    n0 = (tile_id - b * tiles_n) * TOK;
     if (a.skip_halo >= 0) live = n0 < a.lens[b] + a.skip_halo;
   }
 
@@ -988,7 +1008,11 @@ void launch_conv_dk(const ConvGemmArgs& a, hipStream_t s) {
     configured = true;
   }
   dim3 grid(a.B * dx_cdiv(a.N, 128), a.CoutP / TILE);
-  hipLaunchKernelGGL((conv_dk_kernel<TAPS, XH>), grid, dim3(512), smem, s, a);
+  ConvGemmArgs b = a;
+  static const int swz_env = getenv("DX_DK_SWIZZLE") ? atoi(getenv("DX_DK_SWIZZLE")) : 1;
+  b.xcd_swizzle = swz_env && grid.y > 1 && (grid.y <= 4 || grid.y % 4 == 0);
+  if (b.xcd_swizzle) grid.x = dx_roundup(grid.x, 8);
+  hipLaunchKernelGGL((conv_dk_kernel<TAPS, XH>), grid, dim3(512), smem, s, b);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -61,6 +61,15 @@ class Lengths:
         # inference.GraphedSynthesizer: padded-shape buckets (exist = the batch's true longest length) and the batched accent encoder
         # (exist = lengths: every reference behaves as if it were run alone, scripts/synthesize.py:420-448).
         self.exist = None
+        self._order = None
+
+    @property
+    def order(self):
+        """device int32 [B]: utterance indices, longest first (ops.length_order) -- computed by one tiny launch on first use (under graph
+        capture: recorded, so every replay re-derives it from the static length buffer).  Attention workgroups are handed out in this order."""
+        if self._order is None:
+            self._order = ops.length_order(self.i32)
+        return self._order
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -166,7 +175,7 @@ class FFTBlockFn(torch.autograd.Function):
         qkv = qkv_pre if qkv_pre is not None else \
             ops.conv_gemm(x, packs['in'], in_b, lens=L, halo=0, out_dtype=hd, prec=prec)     # bf16 mode: attention reads bf16 q/k/v
         so = rt.seed_offset                        # device scalar added to the seeds (graph replays), or None
-        att, lse = ops.attention_fwd(qkv, lens.i32, heads, s_attn, p_attn, prec=prec, seed_offset=so, ctx_dtype=hd)   # 16-bit modes: 16-bit context
+        att, lse = ops.attention_fwd(qkv, lens.i32, heads, s_attn, p_attn, prec=prec, seed_offset=so, ctx_dtype=hd, order=lens.order)   # 16-bit modes: 16-bit context
         sh = ops.gemm_shadow(prec)                 # bf16 mode: GEMM operands also exist as bf16 copies written by their producers
         if ops.proj_ln_applies(att, packs['out'], prec):   # out-projection + dropout + residual + LayerNorm: one launch, z1 straight from LDS
             z1, y1, mean1, rstd1, *rest = ops.proj_ln_fwd(att, packs['out'], out_b, x, ln1_w, ln1_b, None, lens.i32, seed_pre=s_ln1, p_pre=p_attn,
@@ -253,7 +262,7 @@ class FFTBlockFn(torch.autograd.Function):
         dout_w, dout_b = ops.conv_wgrad(dproj, att, packs['out'], L, 0, arena=arena, w_sink=g('out_w'), b_sink=g('out_b'), prec=prec, defer=True)
         if datt is None:
             datt = ops.conv_gemm(dproj, packs['out'], None, transpose=True, lens=L, halo=0, prec=prec, out_dtype=att.dtype)   # stored like the context
-        dqkv = ops.attention_bwd(qkv, att, datt, lse, L, ctx.heads, s_attn, p_attn, out_dtype=qkv.dtype, prec=prec, seed_offset=so)
+        dqkv = ops.attention_bwd(qkv, att, datt, lse, L, ctx.heads, s_attn, p_attn, out_dtype=qkv.dtype, prec=prec, seed_offset=so, order=lens.order)
         din_w, din_b = ops.conv_wgrad(dqkv, x, packs['in'], L, 0, arena=arena, w_sink=g('in_w'), b_sink=g('in_b'), prec=prec, defer=True)
         dx = ops.conv_gemm(dqkv, packs['in'], None, transpose=True, out=dz1, accumulate=True, lens=L, halo=0, prec=prec)  # + residual branch
         return (dx, dfilm, None, None, None, None,

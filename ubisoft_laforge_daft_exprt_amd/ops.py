@@ -531,8 +531,19 @@ def colsum(x, C=None):
     return out
 
 
-def attention_fwd(qkv, lens, heads, seed, p_drop, prec=None, seed_offset=None, ctx_dtype=torch.float32):
-    """``ctx_dtype``: storage type of the context (the 16-bit type of the operand mode, or float32)."""
+_ATTN_ORDER = os.environ.get('DX_ATTN_ORDER', '1') != '0'
+
+
+def length_order(lens_i32):
+    """Utterance indices sorted by length, longest first (device int32 [B]): the ``order`` argument of the attention wrappers."""
+    order = torch.empty_like(lens_i32)
+    lib().dx_length_order(_p(lens_i32), _p(order), lens_i32.shape[0], _stream())
+    return order
+
+
+def attention_fwd(qkv, lens, heads, seed, p_drop, prec=None, seed_offset=None, ctx_dtype=torch.float32, order=None):
+    """``ctx_dtype``: storage type of the context (the 16-bit type of the operand mode, or float32).
+    ``order``: optional ``length_order(lens)``: the longest utterances' workgroups are dispatched first."""
     B, N, D3 = qkv.shape
     D = D3 // 3
     ctx = torch.empty(B, N, D, dtype=ctx_dtype, device=qkv.device)
@@ -540,11 +551,11 @@ def attention_fwd(qkv, lens, heads, seed, p_drop, prec=None, seed_offset=None, c
     prec = prec or DEFAULT.precision
     _check_h16(prec, qkv, ctx)
     _fn('dx_attention_fwd', prec)(_p(qkv), _rows(qkv), _p(lens), _p(ctx), D, _p(lse), B, N, heads, D, seed, _p(seed_offset), float(p_drop),
-                           _half(prec), _is_bf16(qkv), _is_bf16(ctx), _stream())
+                           _half(prec), _is_bf16(qkv), _is_bf16(ctx), _p(order if _ATTN_ORDER else None), _stream())
     return ctx, lse
 
 
-def attention_bwd(qkv, ctx, dctx, lse, lens, heads, seed, p_drop, out_dtype=torch.float32, prec=None, seed_offset=None):
+def attention_bwd(qkv, ctx, dctx, lse, lens, heads, seed, p_drop, out_dtype=torch.float32, prec=None, seed_offset=None, order=None):
     B, N, D3 = qkv.shape
     D = D3 // 3
     if dctx.dtype != ctx.dtype:
@@ -554,7 +565,7 @@ def attention_bwd(qkv, ctx, dctx, lse, lens, heads, seed, p_drop, out_dtype=torc
     prec = prec or DEFAULT.precision
     _fn('dx_attention_bwd', prec)(_p(qkv), _rows(qkv), _p(ctx), _p(dctx), _rows(dctx), _p(lse), _p(delta), _p(lens), _p(dqkv), _rows(dqkv),
                            B, N, heads, D, seed, _p(seed_offset), float(p_drop), _half(prec), _is_bf16(qkv), _is_bf16(dqkv), _is_bf16(ctx),
-                           _stream())
+                           _p(order if _ATTN_ORDER else None), _stream())
     return dqkv
 
 
