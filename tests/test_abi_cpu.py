@@ -170,3 +170,23 @@ def test_every_launching_entry_point_can_be_priced():
     # valid rows, not padded rows, are credited
     a = dict(B=3, N=12, Cin=128, Cout=128, taps=3, bf16=1, x_bf16=0, y_bf16=0, aux_bf16=0, accumulate=0, relu_aux=0, lens=1)
     assert profiling.price('dx_conv_gemm', a, geom)[2] == 2.0 * 3 * 128 * 128 * (5 + 9 + 12)
+
+
+def test_gradient_kernels_use_no_packed_fma_that_reads_the_high_half_into_the_low_result():
+    """Round 2's "lost update" was bisected (round 3, tools/experiment_fork_wgrad.py) to ``v_pk_fma_f32 ... op_sel:[0,1,0]`` -- the form
+    hipcc chose for the middle tap of ``scalar_conv_wgrad_kernel`` -- returning wrong low results while an MFMA kernel of another
+    stream shared the CUs.  The kernel now spells its tap products as single ``v_fma_f32`` instructions; this test compiles the source
+    to gfx950 assembly and checks that no packed FMA of that form is left anywhere in the file that holds the row / gradient kernels."""
+    import os, shutil, subprocess, tempfile
+    if shutil.which('hipcc') is None:
+        import pytest
+        pytest.skip('hipcc not on PATH')
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'ubisoft_laforge_daft_exprt_amd', 'csrc')
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, 'dx_rows.s')
+        subprocess.run(['hipcc', '-O3', '--offload-arch=gfx950', '-std=c++17', '-S', '--cuda-device-only', '-o', out, os.path.join(csrc, 'dx_rows.hip')],
+                       check=True, stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    bad = [ln.strip() for ln in text.splitlines() if 'v_pk_fma_f32' in ln and 'op_sel:[0,1' in ln]
+    assert not bad, bad[:4]
+    assert 'scalar_conv_wgrad_kernel' in text

@@ -282,6 +282,68 @@ def test_c2_later_phases_with_bucket_traffic_on_another_queue(pkg, c2):
     red.remove()
 
 
+def test_c2_gradients_with_decoder_weight_gradients_on_a_side_stream(pkg, c2):
+    """Round 2's "lost update", as a regression test.  With the frame decoder's queued k = 1 weight gradients (an MFMA kernel) launched on
+    a SIDE stream beside the upsampler's backward, the energy / pitch projection gradients came out wrong on the middle tap of the even
+    channels >= 64 in about half of the steps (1e-2 of the sum).  Round 3 reproduced it (tools/experiment_fork_wgrad.py) and bisected it
+    to the packed form the compiler chose for that tap in ``scalar_conv_wgrad_kernel`` (v_pk_fma_f32 ... op_sel:[0,1,0]); written as single
+    v_fma_f32 instructions the kernel is exact beside any other kernel (24 of 24 steps, against 11 of 24).  Here: 8 forked steps, every
+    gradient equal to the serial step's."""
+    from ubisoft_laforge_daft_exprt_amd import ops
+    from ubisoft_laforge_daft_exprt_amd.trainer import Trainer
+    hp, batch, _ = c2
+    hp = hp.without_dropout() if hasattr(hp, 'without_dropout') else hp
+    pkg.set_precision('bf16')
+    try:
+        model = pkg.DaftExprt(hp).to(DEV)
+        model.load_state_dict(helpers.golden_state_dict(), strict=True)
+        crit = pkg.DaftExprtLoss(DEV, hp)
+        crit.load_pitch_predictor(helpers.golden_pitch_predictor_state_dict())
+    finally:
+        pkg.set_precision('f32')
+    t = Trainer(model, crit, hp, use_graphs=False, cuts=0)
+    rt = model.runtime
+    dev_batch = tuple(x.to(DEV) if torch.is_tensor(x) else x for x in batch)
+    parsed, _ = t._parse([dev_batch])
+    side = torch.cuda.Stream()
+    state = {'fork': False, 'keep': []}
+    original = ops.upsample_bwd
+
+    def upsample_bwd(*a, **kw):               # first call of the upsampler's backward: the decoder's backward has been issued
+        if state['fork']:
+            k1 = {k: v for k, v in rt.wgrad_queue.items() if k[0] == 1}
+            for k in k1:
+                del rt.wgrad_queue[k]
+            state['keep'].append(k1)          # the operands stay referenced until the streams are joined
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                rest, rt.wgrad_queue = rt.wgrad_queue, dict(k1)
+                ops.flush_wgrads(rt)
+                rt.wgrad_queue = rest
+        return original(*a, **kw)
+
+    def step(fork):
+        state['fork'] = fork
+        t._phases(parsed, ITERATION, t.reducer.launch_group)
+        torch.cuda.current_stream().wait_stream(side)
+        state['keep'].clear()
+        t.reducer.finish()
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    ops.upsample_bwd = upsample_bwd
+    try:
+        serial = step(False)
+        for _ in range(8):
+            got = step(True)
+            worst = max(((float((got[k] - serial[k]).abs().max() / serial[k].abs().max().clamp_min(1e-30)), k) for k in serial))
+            assert worst[0] < 1e-3, worst
+    finally:
+        ops.upsample_bwd = original
+        t.reducer.remove()
+    print(f'C2 bf16: decoder k = 1 weight gradients on a side stream vs serial, worst relative difference {worst[0]:.2e} at {worst[1]}')
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # C4: B = 256 inference
 # ----------------------------------------------------------------------------------------------------------------------

@@ -10,7 +10,8 @@ import re
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(PKG), 'include', 'daft_exprt_hip.h')
-LIB_PATH = os.path.join(PKG, 'libdaft_exprt_hip.so')
+# DX_LIB_PATH: a diagnostic build of the SAME library (tools/ablation_build.py: timing ablations of one source file); never a fallback
+LIB_PATH = os.environ.get('DX_LIB_PATH') or os.path.join(PKG, 'libdaft_exprt_hip.so')
 
 _SCALARS = {'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float, 'double': ctypes.c_double,
             'uint64_t': ctypes.c_uint64, 'uint32_t': ctypes.c_uint32}

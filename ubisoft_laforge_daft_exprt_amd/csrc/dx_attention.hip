@@ -486,6 +486,28 @@ __device__ __forceinline__ void store4(dx_h16* p, float a, float b, float c, flo
   *reinterpret_cast<bf16x4*>(p) = h;
 }
 #define DX_MFMA_BF16(A, B, C) DX_MFMA_H16((A), (B), (C))
+// Timing ablations (tools/ablation_build.py; results are then numerically wrong on purpose): DX_ATTN_ABL = 1: no exp2 (p = s);
+// 2: key / query tiles are staged once and reused (no LDS stores, barriers or global loads in the loop); 3: the first products
+// (S, dP) are skipped; 4: the second products (O, dV, dK, dQ) are skipped.
+#ifndef DX_ATTN_ABL
+#define DX_ATTN_ABL 0
+#endif
+#if DX_ATTN_ABL == 1
+#define DX_EXP2(X) (X)
+#else
+#define DX_EXP2(X) __builtin_amdgcn_exp2f(X)
+#endif
+#if DX_ATTN_ABL == 3
+#define DX_MFMA_1ST(A, B, C) (C)
+#else
+#define DX_MFMA_1ST(A, B, C) DX_MFMA_H16((A), (B), (C))
+#endif
+#if DX_ATTN_ABL == 4
+#define DX_MFMA_2ND(A, B, C) (C)
+#else
+#define DX_MFMA_2ND(A, B, C) DX_MFMA_H16((A), (B), (C))
+#endif
+__device__ __forceinline__ float dx_max2(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, INFINITY); }   // no NaNs here: scores are finite or -inf
 // (fmaxf() makes hipcc canonicalise every operand first - a v_max_f32 x, x, x each, 16 per key tile.  An inline-asm v_max3_f32 on the
 // MFMA results avoids that but is WRONG: the compiler's hazard recogniser does not look inside inline asm, so the asm read the
 // accumulators before the matrix pipe had written them - maxima of stale data, a 0.4 % output error that the eager-vs-graph
@@ -530,13 +552,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a_
   DX_TILE_LOAD(QT, vreg, base, a.ld, 2 * a.D + h * HD, 0, a.N)
   for (int kt0 = 0; kt0 < ntiles; ++kt0) {
     const int kbase = kt0 * 64;
+    if (DX_ATTN_ABL != 2 || kt0 == 0) {
     __syncthreads();
     DX_TILE_STORE(QT, kreg, Ks)
     DX_TILE_STORE(QT, vreg, Vs)
     __syncthreads();
-    if (kt0 + 1 < ntiles) {
+    if (kt0 + 1 < ntiles && DX_ATTN_ABL != 2) {
       DX_TILE_LOAD(QT, kreg, base, a.ld, a.D + h * HD, kbase + 64, a.N)
       DX_TILE_LOAD(QT, vreg, base, a.ld, 2 * a.D + h * HD, kbase + 64, a.N)
+    }
     }
     f32x4 st[4];
     float mx = -INFINITY;
@@ -545,18 +569,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a_
     for (int kt = 0; kt < 4; ++kt) {
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) acc = DX_MFMA_BF16(row_frag(Ks, kt * 16 + r, ks, g), qf[ks], acc);
+      for (int ks = 0; ks < 2; ++ks) acc = DX_MFMA_1ST(row_frag(Ks, kt * 16 + r, ks, g), qf[ks], acc);
       if (tail_tile) {                                  // only the last key tile of a row can hold padding keys
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (kbase + kt * 16 + g * 4 + e >= len) acc[e] = -INFINITY;
       }
-      mx = fmaxf(fmaxf(mx, fmaxf(acc[0], acc[1])), fmaxf(acc[2], acc[3]));
+      // max(a, b) as med3(a, b, +inf): ONE instruction on the accumulators.  fmaxf() makes hipcc canonicalise every operand first (a
+      // v_max_f32 x, x each: 16 extra instructions per key tile in a VALU-bound loop); v_med3_f32 is not an IEEE maxnum and gets none.
+      mx = dx_max2(mx, dx_max2(dx_max2(acc[0], acc[1]), dx_max2(acc[2], acc[3])));
       st[kt] = acc;
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
+    mx = dx_max2(mx, __shfl_xor(mx, 16, 64));
+    mx = dx_max2(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = dx_max2(m_run, mx);
     // the running maxima settle after the first tiles: the rescale of O and l (an exp + 17 multiplies per lane) runs only in a
     // tile where some query of the wave saw a new maximum (wave-uniform branch)
     const bool rescale = __builtin_amdgcn_ballot_w64(m_new > m_run) != 0;
@@ -566,7 +592,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a_
       float pk[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        pk[e] = __builtin_amdgcn_exp2f(st[kt][e] - m_new);
+        pk[e] = DX_EXP2(st[kt][e] - m_new);
         ls += pk[e];
       }
       // dropped probabilities become 0; the 1/(1-p) factor of the kept ones is applied once to O at the end
@@ -590,8 +616,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a_
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       f32x4 acc = o[dt];
-      acc = DX_MFMA_BF16(tr_pair(Vs, 0 + g * 4, 16 + g * 4, dt * 16, lane), p01, acc);
-      acc = DX_MFMA_BF16(tr_pair(Vs, 32 + g * 4, 48 + g * 4, dt * 16, lane), p23, acc);
+      acc = DX_MFMA_2ND(tr_pair(Vs, 0 + g * 4, 16 + g * 4, dt * 16, lane), p01, acc);
+      acc = DX_MFMA_2ND(tr_pair(Vs, 32 + g * 4, 48 + g * 4, dt * 16, lane), p23, acc);
       o[dt] = acc;
     }
   }
@@ -661,6 +687,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
   if (g == 0 && qrow < a.N) a.delta_out[(size_t)bh * a.N + qrow] = delta_q;
   const float lse_q = a.lse[(size_t)bh * a.N + qload];
   const float neg_delta_q = -delta_q;
+  const f32x4 neg_lse4 = f32x4{-lse_q, -lse_q, -lse_q, -lse_q};
   f32x4 dq[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -684,7 +711,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
     const bool tail_tile = kbase + 64 > len;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+      // S' = K Q^T - lse: the row constant is the INITIAL accumulator of the chain (a lane owns one query: the same four registers for
+      // every key tile), so p = exp2(S') needs no subtraction (16 instructions per key tile in a VALU-bound loop)
+      f32x4 s = neg_lse4, dp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         s = DX_MFMA_BF16(row_frag(Ks, kt * 16 + r, ks, g), qf[ks], s);
@@ -696,7 +725,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
       if (a.thresh) dx_keep4(dx_rand64(a.seed, drow | (uint64_t)((kbase + kt * 16 + g * 4) >> 2)), thresh_v, u, neg_delta_q);
       float p[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) p[e] = __builtin_amdgcn_exp2f(s[e] - lse_q);
+      for (int e = 0; e < 4; ++e) p[e] = __builtin_amdgcn_exp2f(s[e]);
       if (tail_tile) {                                    // wave-uniform: only the last key tile can hold padding keys
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -731,7 +760,7 @@ __global__ __launch_bounds__(256, (sizeof(QT) == 2 && sizeof(CT) == 2) ? 3 : 2) 
   if (a.seed_offset) a.seed += *a.seed_offset;
   __shared__ __attribute__((aligned(16))) unsigned char Qs[64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char Gs[64 * 128];
-  __shared__ float lse_s[64], delta_s[64];
+  __shared__ __attribute__((aligned(16))) float lse_s[64], delta_s[64];
   const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
@@ -774,12 +803,14 @@ __global__ __launch_bounds__(256, (sizeof(QT) == 2 && sizeof(CT) == 2) ? 3 : 2) 
   if (tid < 64 && tid < a.N) { lse_r = a.lse[(size_t)bh * a.N + tid]; delta_r = a.delta[(size_t)bh * a.N + tid]; }
   for (int qt0 = 0; qt0 < ntiles; ++qt0) {
     const int qbase = qt0 * 64;
+    if (DX_ATTN_ABL != 2 || qt0 == 0) {
     __syncthreads();
     DX_TILE_STORE(QT, qreg, Qs)
     DX_TILE_STORE(CT, greg, Gs)
-    if (tid < 64) { lse_s[tid] = lse_r; delta_s[tid] = delta_r; }
+    if (tid < 64) { lse_s[tid] = -lse_r; delta_s[tid] = delta_r; }     // (-lse: see the S' accumulator below)
     __syncthreads();
-    if (qt0 + 1 < ntiles) {
+    }
+    if (qt0 + 1 < ntiles && DX_ATTN_ABL != 2) {
       DX_TILE_LOAD(QT, qreg, base, a.ld, h * HD, qbase + 64, a.N)
       DX_TILE_LOAD(CT, greg, gbase, a.ldc, h * HD, qbase + 64, a.N)
       const int qn = qbase + 64 + tid;
@@ -805,15 +836,16 @@ __global__ __launch_bounds__(256, (sizeof(QT) == 2 && sizeof(CT) == 2) ? 3 : 2) 
           const uint64_t w = dx_rand64(a.seed, drop_index(bh, a.N, qbase + qt * 16 + g * 4 + (r & 3), krow) >> 2);
           wlo = (uint32_t)w; whi = (uint32_t)(w >> 32);
         }
-        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+        // S' = Q K^T - lse: -lse of the lane's four query rows (staged negated) is the initial accumulator, p = exp2(S') needs no subtraction
+        f32x4 s = *reinterpret_cast<const f32x4*>(&lse_s[qt * 16 + g * 4]), dp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          s = DX_MFMA_BF16(row_frag(Qs, qt * 16 + r, ks, g), kf[ks], s);
-          dp = DX_MFMA_BF16(row_frag(Gs, qt * 16 + r, ks, g), vf[ks], dp);
+          s = DX_MFMA_1ST(row_frag(Qs, qt * 16 + r, ks, g), kf[ks], s);
+          dp = DX_MFMA_1ST(row_frag(Gs, qt * 16 + r, ks, g), vf[ks], dp);
         }
         float p[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) p[e] = __builtin_amdgcn_exp2f(s[e] - lse_s[qt * 16 + g * 4 + e]);
+        for (int e = 0; e < 4; ++e) p[e] = DX_EXP2(s[e]);
         if (tail_k || tail_q) {                             // wave-uniform: padding keys / queries exist only in the last tiles
 #pragma unroll
           for (int e = 0; e < 4; ++e)
@@ -841,8 +873,8 @@ __global__ __launch_bounds__(256, (sizeof(QT) == 2 && sizeof(CT) == 2) ? 3 : 2) 
       const bf16x8 pp = pack_pair(pd[0], pd[1]), dd = pack_pair(ds[0], ds[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        dv[dt] = DX_MFMA_BF16(tr_pair(Gs, half * 32 + g * 4, half * 32 + 16 + g * 4, dt * 16, lane), pp, dv[dt]);
-        dk[dt] = DX_MFMA_BF16(tr_pair(Qs, half * 32 + g * 4, half * 32 + 16 + g * 4, dt * 16, lane), dd, dk[dt]);
+        dv[dt] = DX_MFMA_2ND(tr_pair(Gs, half * 32 + g * 4, half * 32 + 16 + g * 4, dt * 16, lane), pp, dv[dt]);
+        dk[dt] = DX_MFMA_2ND(tr_pair(Qs, half * 32 + g * 4, half * 32 + 16 + g * 4, dt * 16, lane), dd, dk[dt]);
       }
     }
   }
@@ -856,6 +888,9 @@ __global__ __launch_bounds__(256, (sizeof(QT) == 2 && sizeof(CT) == 2) ? 3 : 2) 
   }
 }
 #undef DX_MFMA_BF16
+#undef DX_MFMA_1ST
+#undef DX_MFMA_2ND
+#undef DX_EXP2
 #undef DX_TILE_LOAD
 #undef DX_TILE_STORE
 

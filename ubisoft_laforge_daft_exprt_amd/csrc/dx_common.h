@@ -73,17 +73,20 @@ __device__ __forceinline__ float dx_wave_max(float v) {
 
 // ---- counter-based dropout RNG -----------------------------------------------------------------
 // Counter-based draw for (seed, index): 64 random bits = four 16-bit keep/drop decisions.  The same (seed, index) is
-// evaluated again in the backward kernels, so no mask tensor is stored.  Built from 32-bit multiplies (murmur3's block mix and
-// finaliser over the two halves, each half folded into the other): the attention kernels are VALU-bound with dropout on, and
-// splitmix64's three 64-bit multiplies cost twice as many 32-bit multiplier passes.  (Keep rate, cross-field, lag-1 and
-// seed/seed+1 correlations of the keep mask checked on 4 M consecutive and on attention-shaped indices: all at noise level.)
+// evaluated again in the backward kernels, so no mask tensor is stored.  The attention kernels are VALU-bound with dropout on
+// (a wave64 vector instruction takes 4 cycles; ~40 % of their instructions were this function), so the mixer is as short as the
+// statistics allow: the high halves of index and seed are folded in by one multiply (loop-invariant in every caller: hoisted), the
+// low word is a two-round multiply-xorshift finaliser (the "lowbias32" constants), the high word one more multiply-xorshift of the
+// low one: 3 multiplies in the loop instead of 6, ~13 instructions instead of ~22.  Keep rate per field, cross-field, lag-1 along
+// keys / rows / consecutive indices, seed vs seed + 1 correlations and byte uniformity of the keep mask are all at noise level on
+// 4 M attention-shaped and 4 M consecutive indices (tests/test_host_glue_cpu.py restates the function in numpy and checks them).
 __device__ __forceinline__ uint64_t dx_rand64(uint64_t seed, uint64_t idx) {
-  uint32_t a = (uint32_t)idx ^ (uint32_t)seed;
-  uint32_t b = (uint32_t)(idx >> 32) ^ (uint32_t)(seed >> 32);
-  a *= 0xCC9E2D51u; a = (a << 15) | (a >> 17); a *= 0x1B873593u;
-  b = (b ^ a) * 0x85EBCA6Bu; b ^= b >> 13; b *= 0xC2B2AE35u; b ^= b >> 16;
-  a ^= b; a ^= a >> 16; a *= 0x85EBCA6Bu; a ^= a >> 13; a *= 0xC2B2AE35u; a ^= a >> 16;
-  return ((uint64_t)b << 32) | a;
+  uint32_t x = (uint32_t)idx ^ (uint32_t)seed;
+  const uint32_t hi = (uint32_t)(idx >> 32) ^ (uint32_t)(seed >> 32);
+  x ^= hi * 0x9E3779B1u;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  uint32_t y = (x ^ 0x85EBCA6Bu) * 0xC2B2AE35u; y ^= y >> 15;
+  return ((uint64_t)y << 32) | x;
 }
 __device__ __forceinline__ float dx_dropout_scale(uint64_t seed, uint64_t elem, uint32_t thresh16, float inv_keep) {
   uint64_t r = dx_rand64(seed, elem >> 2);

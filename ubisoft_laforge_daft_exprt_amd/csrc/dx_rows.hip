@@ -530,14 +530,37 @@ __global__ __launch_bounds__(256) void scalar_conv_wgrad_kernel(const float* __r
   f32x4 a0[3], a1[3], ab = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < 3; ++t) { a0[t] = f32x4{0.f, 0.f, 0.f, 0.f}; a1[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  // The tap products are written as single v_fma_f32 instructions on purpose.  Left to the compiler, a0[1] += g * xs[0][i + 1] becomes
+  // v_pk_fma_f32 ... op_sel:[0,1,0] (the LOW result reads the HIGH register of the (xs[i], xs[i + 1]) pair a ds_read2_b32 delivered), and
+  // that form returned wrong low results -- the even channels >= 64 of the middle tap, a random subset per launch, 1e-2 of the sum --
+  // whenever an MFMA kernel of another stream shared the CUs (round 2's "lost update"; reproduced and bisected to this instruction form
+  // in round 3: tools/experiment_fork_wgrad.py).  Alone on the chip, or in this form, the kernel is exact.
+#ifndef DX_SCW_PACKED
+#define DX_SCW_PACKED 0
+#endif
 #pragma unroll 4
   for (int n = n_begin + grp; n < n_end; n += 8) {
     f32x4 g = *reinterpret_cast<const f32x4*>(dout + ((size_t)b * N + n) * ldd + q * 4);
     const int i = n - n_begin;
     g *= rsc[i];
     ab += g;
+#if DX_SCW_PACKED
 #pragma unroll
     for (int t = 0; t < 3; ++t) { a0[t] += g * xs[0][i + t]; a1[t] += g * xs[1][i + t]; }
+#else
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const float x0 = xs[0][i + t], x1 = xs[1][i + t];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float acc0 = a0[t][e], acc1 = a1[t][e];
+        const float ge = g[e];
+        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc0) : "v"(ge), "v"(x0));
+        asm("v_fma_f32 %0, %1, %2, %0" : "+v"(acc1) : "v"(ge), "v"(x1));
+        a0[t][e] = acc0; a1[t][e] = acc1;
+      }
+    }
+#endif
   }
   // the eight row groups fold in LDS first: every atomic lands on one of ~1 k addresses and same-address atomics serialise
   __shared__ float fold[8][7][D];
