@@ -50,8 +50,25 @@ def main():
     rows = [('two launches fwd', timeit(unfused_fwd)), ('fused fwd', timeit(lambda: ops.ff_pair(x, p1, p2, b1, b2, lens))),
             ('two launches bwd', timeit(unfused_bwd)),
             ('fused bwd', timeit(lambda: ops.ff_pair(dz, p1, p2, None, None, lens, backward=True, aux=h, out=base, accumulate=True)))]
+    # the forms the model launches: + LayerNorm epilogue (+ the next block's q/k/v), and the whole feed-forward half of the block's backward
+    ln_w, ln_b = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+    film = rn(B, 2 * D)
+    win, bin_ = rn(3 * D, D, sc=1 / math.sqrt(D)), rn(3 * D, sc=0.1)
+    pin = ops.PackedWeight(win)
+    wout = rn(D, D, sc=1 / math.sqrt(D))
+    pout = ops.PackedWeight(wout)
+    res = rn(B, N, D)
+    rows.append(('fwd + LN epilogue', timeit(lambda: ops.ff_pair_ln(x, p1, p2, b1, b2, lens, res, ln_w, ln_b, film, seed_pre=5, p_pre=0.1))))
+    rows.append(('fwd + LN + next qkv', timeit(lambda: ops.ff_pair_ln(x, p1, p2, b1, b2, lens, res, ln_w, ln_b, film, seed_pre=5, p_pre=0.1, next_in=(pin, bin_)))))
+    z2, _, _, mean2, rstd2 = ops.ff_pair_ln(x, p1, p2, b1, b2, lens, res, ln_w, ln_b, film, seed_pre=5, p_pre=0.1)
+    z1, mean1, rstd1 = rn(B, N, D), rn(B, N), rn(B, N).abs() + 0.5
+    dy2 = rn(B, N, D) * valid
+    rows.append(('block bwd (LN2b+pair+LN1b)', timeit(lambda: ops.ff_block_bwd(dy2, z2, mean2, rstd2, ln_w, ln_b, film, p1, p2, lens, h, z1, mean1, rstd1, ln_w, ln_b,
+                                                                               seed2=5, p2=0.1, seed1=6, p1=0.1))))
+    rows.append(('block bwd + datt', timeit(lambda: ops.ff_block_bwd(dy2, z2, mean2, rstd2, ln_w, ln_b, film, p1, p2, lens, h, z1, mean1, rstd1, ln_w, ln_b,
+                                                                     seed2=5, p2=0.1, seed1=6, p1=0.1, out_pack=pout))))
     for name, us in rows:
-        print(f'{axis}-level B={B} N={N} valid tokens={tokens}: {name:18s} {us:8.1f} us   {flops / us / 1e6:7.1f} TFLOP/s algorithmic '
+        print(f'{axis}-level B={B} N={N} valid tokens={tokens}: {name:28s} {us:8.1f} us   {flops / us / 1e6:7.1f} TFLOP/s algorithmic '
               f'({100 * flops / us / 1e6 / 2500:.1f} % of 2.5 PF)')
 
 

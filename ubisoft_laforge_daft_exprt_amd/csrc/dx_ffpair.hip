@@ -38,9 +38,22 @@
 
 namespace {
 
-constexpr int FP_TOK = 126;      // output tokens per workgroup
-constexpr int FP_HR = 130;       // rows of an LDS activation image (x: 130 used; hidden: 128 used + 2 zero rows)
-constexpr int FP_IMG = 2 * FP_HR * 128;   // bytes of one image: [2 chunks of 64 channels][130 rows][128 B]
+// NJ = MFMA column tiles (16 tokens each) of a workgroup's token tile.  NJ = 8 (126 output tokens, 100 KB of LDS, 256 registers: ONE workgroup
+// per CU) was the round-2 kernel: 29 % of such a workgroup's life is fill (the first slice is produced with the consumers idle), drain and the
+// row-pass epilogues, during which the CU's matrix pipes idle.  NJ = 4 (62 output tokens, 51 KB, <= 128 registers) lets TWO workgroups share
+// a CU: four waves per SIMD, and one workgroup's fill / drain / epilogue runs beside the other's slice loop.  The price: every weight
+// fragment is reused by 4 instead of 8 MFMAs, i.e. twice the L2 -> register weight traffic per FLOP (768 MB per launch), and at the
+// 128-register cap the kernel spills 41-45 registers.  MEASURED (round 3, C2 frame axis, same box): NJ = 4 is slower -- forward 80-93 us
+// against 56, backward 96-101 against 68 -- so NJ = 8 stays the default and NJ = 4 is kept only as the recorded experiment (DX_FF_NJ=4).
+template <int NJ> struct FP {
+  static constexpr int NROW = NJ * 16;       // hidden rows of a tile = MFMA columns of the first conv
+  static constexpr int TOK = NROW - 2;       // output tokens per workgroup
+  static constexpr int HR = NROW + 2;        // rows of an LDS activation image (x: HR used; hidden: NROW used + 2 zero rows)
+  static constexpr int IMG = 2 * HR * 128;   // bytes of one image: [2 chunks of 64 channels][HR rows][128 B]
+  static constexpr int XP = (HR * 16 + 511) / 512;     // passes of 512 threads over the HR x 16 staging units
+  static constexpr int RP = (HR + 31) / 32;            // passes of 32 rows (16 lanes x 8 channels per row) over the HR rows
+};
+constexpr int FP_TOK = FP<8>::TOK;           // (host-side helpers and the Python side's "126-token tile" refer to the NJ = 8 geometry)
 
 struct FFPairArgs {
   const dx_h16* X; int ldx;
@@ -77,6 +90,7 @@ struct FFPairArgs {
   const float* lnp_film; int lnp_ld_film;
   dx_h16* lnp_dg; float* lnp_dw; float* lnp_db; float* lnp_dfilm; int lnp_ld_dfilm;
   unsigned long long lnp_seed; unsigned lnp_thresh; float lnp_inv_keep;
+  int slice_skew;                    // 1: workgroup w starts its walk over the hidden slices at slice w % nslices (see the kernel)
   unsigned long long* stamps;        // diagnostic builds (-DDX_FFPAIR_STAMPS, tools/ffpair_stamps.py) only: [workgroup][role][16] s_memtime values
 };
 
@@ -117,8 +131,9 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 #define FP_MMA(W, X, C) C = DX_MFMA_H16(__builtin_bit_cast(bf16x8, W), __builtin_bit_cast(bf16x8, X), C);
 
 // AUX: backward (mid = sign mask of the stored forward activation); RELU: forward (mid = ReLU)
-template <bool AUX, bool RELU>
-__global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
+template <bool AUX, bool RELU, int NJ>
+__global__ __launch_bounds__(512, NJ == 8 ? 2 : 4) void ff_pair_kernel(const FFPairArgs a) {
+  constexpr int FP_TOK = FP<NJ>::TOK, FP_HR = FP<NJ>::HR, FP_IMG = FP<NJ>::IMG, NROW = FP<NJ>::NROW, XP = FP<NJ>::XP, RP = FP<NJ>::RP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const Xs = smem;
   unsigned char* const Hs0 = smem + FP_IMG;
@@ -142,9 +157,18 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
   const int w_i = role == 0 ? 4 * 512 : (a.F >> 5) * 512;                          // between the two row blocks
   const int w_slice = role == 0 ? 8 * 4 * 512 : 4 * 512;                           // between slices
   const int total_steps = nslices * 12;
-  auto w_ptr = [&](int gs) {                          // global step index -> fragment (i = 0) address; past the end: re-read the last
+  // Slice ORDER: iteration `it` of a workgroup handles hidden slice (it + skew) % nslices, skew = its block index.  Every workgroup of a launch
+  // streams the same 1.5 MB of weights; started together and walking the slices in the same order they all ask the XCD's L2 for the
+  // SAME kilobytes at the same time, i.e. for the one or two L2 channels those addresses live in: the fragment stream ran at ~7 TB/s chip-wide
+  // whatever the tile size (126-token tiles: 384 MB per launch in 56 us; 62-token tiles: 768 MB in 93 us).  Skewed, the 32 workgroups of an XCD
+  // are spread over all nslices x 12 steps of the stream.  (A sum over slices in another order: fp32 rounding only; the order is a function of the
+  // block index, so results stay reproducible run to run.)
+  const int skew = a.slice_skew ? (int)((blockIdx.x >> 3) % (unsigned)nslices) : 0;   // (blockIdx & 7 = the XCD: neighbours ON an XCD must differ)
+  auto slice_of = [&](int it) { const int f = it + skew; return f >= nslices ? f - nslices : f; };
+  auto w_ptr = [&](int gs) {                          // global step index (iteration order) -> fragment (i = 0) address; past the end: re-read the last
     gs = min(gs, total_steps - 1);
-    const int f = gs / 12, s = gs - f * 12;
+    const int it_ = gs / 12, s = gs - it_ * 12;
+    const int f = slice_of(it_);
     return wbase + (size_t)f * w_slice + (s >> 2) * w_tap + (s & 3) * 512;
   };
   f32x4 wr[4][2];                                     // ring of 4 steps
@@ -245,10 +269,10 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
     float gw[8], gb[8], gfg[8], gfb[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) gw[e] = gb[e] = gfg[e] = gfb[e] = 0.f;
-    f32x4 dyv[5][2], zv[5][2];
-    float muv[5], rsv[5];
+    f32x4 dyv[RP][2], zv[RP][2];
+    float muv[RP], rsv[RP];
 #pragma unroll
-    for (int it = 0; it < 5; ++it) {                    // all global reads first
+    for (int it = 0; it < RP; ++it) {                   // all global reads first
       const int row = (tid >> 4) + it * 32, n = n0 - 2 + row;
       const bool valid = row < FP_HR && n >= 0 && n < len_b && n < NL;
       const size_t grow = (size_t)b * a.N + n;
@@ -262,7 +286,7 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
     }
     FP_WLOAD(0, 0) FP_WLOAD(1, 1) FP_WLOAD(2, 2) FP_WLOAD(3, 3)      // first weight fragments: in flight beside the row arithmetic
 #pragma unroll
-    for (int it = 0; it < 5; ++it) {
+    for (int it = 0; it < RP; ++it) {
       const int row = (tid >> 4) + it * 32, n = n0 - 2 + row;
       const bool inb = row < FP_HR && n >= 0 && n < a.N;
       const bool owned = inb && row >= 2 && row < 2 + FP_TOK;         // the 126 rows this workgroup writes and sums (halo rows: only the LDS tile)
@@ -337,15 +361,15 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
     }
     __syncthreads();                                     // the scratch is read: the hidden image may be written
     if (tid < 64) {
-      const int img = tid >> 5, rr = 128 + ((tid >> 4) & 1), qq = tid & 15;
+      const int img = tid >> 5, rr = NROW + ((tid >> 4) & 1), qq = tid & 15;
       *reinterpret_cast<f32x4*>((img ? Hs1 : Hs0) + (qq >> 3) * (FP_HR * 128) + fp_lds_off(rr, qq & 7)) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   } else
   // ---- stage the activation tile: rows p = 0..129 <-> n = n0 - 2 + p, zero outside [0, NL) --------------------------------
   {
-    f32x4 xr[5];
+    f32x4 xr[XP];
 #pragma unroll
-    for (int it = 0; it < 5; ++it) {
+    for (int it = 0; it < XP; ++it) {
       const int u = tid + it * 512;
       const int row = u >> 4, q = u & 15;
       const int n = n0 - 2 + row;
@@ -356,11 +380,11 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
     FP_WLOAD(0, 0) FP_WLOAD(1, 1) FP_WLOAD(2, 2) FP_WLOAD(3, 3)      // first weight fragments: in flight beside the tile loads
     // rows 128, 129 of both hidden images stay zero for the whole kernel (the last two MFMA columns of the second conv read them)
     if (tid < 64) {
-      const int img = tid >> 5, rr = 128 + ((tid >> 4) & 1), q = tid & 15;
+      const int img = tid >> 5, rr = NROW + ((tid >> 4) & 1), q = tid & 15;
       *reinterpret_cast<f32x4*>((img ? Hs1 : Hs0) + (q >> 3) * (FP_HR * 128) + fp_lds_off(rr, q & 7)) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int it = 0; it < 5; ++it) {
+    for (int it = 0; it < XP; ++it) {
       const int u = tid + it * 512;
       const int row = u >> 4, q = u & 15;
       if (u < FP_HR * 16) *reinterpret_cast<f32x4*>(Xs + (q >> 3) * (FP_HR * 128) + fp_lds_off(row, q & 7)) = xr[it];
@@ -384,25 +408,25 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
   // stalled all eight waves for ~1 k cycles per iteration, stamped)
 #define FP_CO_RD(K, IMGC)                                                                                            \
   {                                                                                                                  \
-    const int u_ = fp_opaque(tid) + 1024 + (K) * 256;           /* producers (threads 0..255): the upper half of the units */ \
+    const int u_ = fp_opaque(tid) + NROW * 8 + (K) * 256;       /* producers (threads 0..255): the upper half of the units */ \
     const int row_ = u_ >> 4, q_ = u_ & 15;                                                                          \
-    cpv = *reinterpret_cast<const f32x4*>((IMGC) + (q_ >> 3) * (FP_HR * 128) + fp_lds_off(min(row_, 127) + 1, q_ & 7)); \
+    cpv = *reinterpret_cast<const f32x4*>((IMGC) + (q_ >> 3) * (FP_HR * 128) + fp_lds_off(min(row_, NROW - 1) + 1, q_ & 7)); \
   }
 #define FP_CO_ST(K, F0C)                                                                                             \
   {                                                                                                                  \
-    const int u_ = fp_opaque(tid) + 1024 + (K) * 256;                                                                \
+    const int u_ = fp_opaque(tid) + NROW * 8 + (K) * 256;                                                            \
     const int row_ = u_ >> 4, q_ = u_ & 15;                                                                          \
     if (row_ < h_rows) *reinterpret_cast<f32x4*>(a.H + ((size_t)b * a.N + n0 + row_) * a.ldh + (F0C) + q_ * 8) = cpv; \
   }
 #define FP_COPY_OUT_CONS(IMGC, F0C)                                                                                  \
   {                                                                                                                  \
-    f32x4 cv_[4];                                                                                                    \
+    f32x4 cv_[NJ / 2];                                                                                               \
     const int t_ = fp_opaque(tid) - 256;                       /* consumer threads are 256..511: the lower half of the units */ \
-    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                                  \
+    _Pragma("unroll") for (int k = 0; k < NJ / 2; ++k) {                                                                  \
       const int u_ = t_ + k * 256;                                                                                   \
       cv_[k] = *reinterpret_cast<const f32x4*>((IMGC) + ((u_ & 15) >> 3) * (FP_HR * 128) + fp_lds_off((u_ >> 4) + 1, u_ & 7)); \
     }                                                                                                                \
-    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                                  \
+    _Pragma("unroll") for (int k = 0; k < NJ / 2; ++k) {                                                             \
       const int u_ = t_ + k * 256;                                                                                   \
       const int row_ = u_ >> 4, q_ = u_ & 15;                                                                        \
       if (row_ < h_rows) *reinterpret_cast<f32x4*>(a.H + ((size_t)b * a.N + n0 + row_) * a.ldh + (F0C) + q_ * 8) = cv_[k]; \
@@ -415,30 +439,30 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
 #define FP_RD8(DST, IMG, S)                                                                                          \
   {                                                                                                                  \
     const unsigned char* const bp_ = (IMG) + (((S) & 3) >> 1) * (FP_HR * 128) + foff[((S) >> 2) % 3][(S) & 1];       \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) DST[j] = *reinterpret_cast<const float4*>(bp_ + j * 2048);         \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) DST[j] = *reinterpret_cast<const float4*>(bp_ + j * 2048);        \
   }
 #define FP_STEP(CUR, NXT, IMG, GS0, S, AUXPF, FRESH, CO, IMGC, F0C)                                                  \
   {                                                                                                                  \
     if (DX_FP_ABL != 2 && DX_FP_ABL != 4) { if ((S) + 1 < 12) FP_RD8(NXT, IMG, (S) + 1) }                                              \
-    else { _Pragma("unroll") for (int j = 0; j < 8; ++j) NXT[j] = CUR[j]; }                                          \
-    if ((CO) && DX_FP_ABL != 4 && (S) < 8 && ((S) & 1) == 0) FP_CO_RD((S) >> 1, IMGC)                                                  \
+    else { _Pragma("unroll") for (int j = 0; j < NJ; ++j) NXT[j] = CUR[j]; }                                         \
+    if ((CO) && DX_FP_ABL != 4 && (S) < NJ && ((S) & 1) == 0) FP_CO_RD((S) >> 1, IMGC)                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
     const f32x4 w0 = wr[(S) & 3][0], w1 = wr[(S) & 3][1];                                                            \
     if ((FRESH) && (S) == 0) {                                  /* a producer slice starts from the bias as the C operand */ \
-      _Pragma("unroll") for (int j = 0; j < 8; ++j) { acc[0][j] = bv0; FP_MMA(w0, CUR[j], acc[0][j]) }               \
-      _Pragma("unroll") for (int j = 0; j < 8; ++j) { acc[1][j] = bv1; FP_MMA(w1, CUR[j], acc[1][j]) }               \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j) { acc[0][j] = bv0; FP_MMA(w0, CUR[j], acc[0][j]) }              \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j) { acc[1][j] = bv1; FP_MMA(w1, CUR[j], acc[1][j]) }              \
     } else {                                                                                                         \
-      _Pragma("unroll") for (int j = 0; j < 8; ++j) { FP_MMA(w0, CUR[j], acc[0][j]) }                                \
-      _Pragma("unroll") for (int j = 0; j < 8; ++j) { FP_MMA(w1, CUR[j], acc[1][j]) }                                \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j) { FP_MMA(w0, CUR[j], acc[0][j]) }                               \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j) { FP_MMA(w1, CUR[j], acc[1][j]) }                               \
     }                                                                                                                \
     if (DX_FP_ABL != 1 && DX_FP_ABL != 4) FP_WLOAD((S) & 3, (GS0) + (S) + 4)                                                           \
-    if ((CO) && DX_FP_ABL != 4 && (S) < 8 && ((S) & 1) == 1) FP_CO_ST((S) >> 1, F0C)                                                   \
+    if ((CO) && DX_FP_ABL != 4 && (S) < NJ && ((S) & 1) == 1) FP_CO_ST((S) >> 1, F0C)                                                  \
     if ((S) == 8) { AUXPF }                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
   }
 #define FP_SLICE_STEPS(IMG, GS0, AUXPF, FR, CO, IMGC, F0C)                                                           \
   {                                                                                                                  \
-    float4 xa[8], xb[8];                                                                                             \
+    float4 xa[NJ], xb[NJ];                                                                                           \
     f32x4 cpv;                                                                                                       \
     FP_RD8(xa, IMG, 0)                                                                                               \
     FP_STEP(xa, xb, IMG, GS0, 0, AUXPF, FR, CO, IMGC, F0C) FP_STEP(xb, xa, IMG, GS0, 1, AUXPF, FR, CO, IMGC, F0C)    \
@@ -453,35 +477,35 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
   // allocator carry the accumulators of both paths through common phis and rotate them through 64 extra registers.
   unsigned char* const stage = smem;                  // final 128 x 128 fp32 tile: 64 KB over the activation image and the first hidden image
   if (role == 0) {
-    f32x4 acc[2][8];
+    f32x4 acc[2][NJ];
     // hidden rows outside [0, N) are the second conv's zero padding: only the first / last tile of a batch row has any
     const bool edge = n0 == 0 || n0 + FP_TOK >= NL;
     // bias + ReLU (forward) or the sign mask (backward), bf16, into slice image f & 1
 #define FP_PRODUCE(F_, COFLAG)                                                                                       \
     {                                                                                                                \
-      const int f0 = (F_) << 7;                                                                                      \
+      const int f0 = slice_of(F_) << 7;                                                                              \
       /* the bias is the C operand of the slice's first MFMAs: no add in the epilogue */                             \
       const f32x4 bv0 = a.bias_a ? *reinterpret_cast<const f32x4*>(a.bias_a + f0 + 32 * wq + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};      \
       const f32x4 bv1 = a.bias_a ? *reinterpret_cast<const f32x4*>(a.bias_a + f0 + 32 * wq + 16 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f}; \
-      bf16x4 av[2][8];                                                                                               \
+      bf16x4 av[2][NJ];                                                                                              \
       FP_SLICE_STEPS(Xs, (F_) * 12,                                                                                  \
         if constexpr (AUX) {                                                                                         \
           const int r2_ = fp_opaque(r);                                                                              \
           const int g2_ = fp_opaque(g);                                                                              \
           _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                              \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                          \
+            _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                         \
               const int n = min(max(n0 - 1 + 16 * j + r2_, 0), a.N - 1);                                             \
               av[i][j] = *reinterpret_cast<const bf16x4*>(a.aux + ((size_t)b * a.N + n) * a.ld_aux + f0 + 32 * wq + 16 * i + 4 * g2_); \
             }                                                                                                        \
-        }, true, COFLAG, ((((F_) - 1) & 1) ? Hs1 : Hs0), ((F_) - 1) << 7)                                            \
+        }, true, COFLAG, ((((F_) - 1) & 1) ? Hs1 : Hs0), slice_of((F_) - 1) << 7)                                    \
       unsigned char* const out = ((F_) & 1) ? Hs1 : Hs0;                                                             \
       const int r_ = fp_opaque(r);                                                                                   \
       const int g_ = fp_opaque(g);                                                                                   \
-      if (DX_FP_ABL == 3) { _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(acc[i][j])); } \
+      if (DX_FP_ABL == 3) { _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j) asm volatile("" :: "v"(acc[i][j])); } \
       else _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
         const int c = 32 * wq + 16 * i + 4 * g_;                                                                     \
         unsigned char* const orow = out + (c >> 6) * (FP_HR * 128) + fp_lds_off(r_, (c & 63) >> 3) + ((g_ & 1) << 3); \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                              \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                             \
           f32x4 v = acc[i][j];                                                                                       \
           if constexpr (AUX) {                                                                                       \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) if (!((float)av[i][j][e] > 0.f)) v[e] = 0.f;               \
@@ -511,30 +535,30 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
       const unsigned char* const imgc = ((nslices - 1) & 1) ? Hs1 : Hs0;
       f32x4 cpv;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { FP_CO_RD(k, imgc) FP_CO_ST(k, (nslices - 1) << 7) }
+      for (int k = 0; k < NJ / 2; ++k) { FP_CO_RD(k, imgc) FP_CO_ST(k, slice_of(nslices - 1) << 7) }
     }
     __syncthreads();
     FP_STAMP(3 + nslices)
 #undef FP_PRODUCE
   } else {
-    f32x4 acc[2][8];
+    f32x4 acc[2][NJ];
     const f32x4 bv0 = f32x4{0.f, 0.f, 0.f, 0.f}, bv1 = bv0;  // (names the step macro's producer-only branch refers to)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();                                   // iteration 0: the first slice is being produced
     FP_STAMP(3)
     for (int it = 1; it <= nslices; ++it) {
       if (it == 4) FP_STAMP(12)
-      const int f = it - 1;
+      const int f = it - 1;                              // iteration whose slice is consumed; its hidden channels start at slice_of(f) * 128
       const unsigned char* const img = (f & 1) ? Hs1 : Hs0;
       // The consumers copy their half of the finished slice out BEFORE their matrix steps (4 pieces per thread; the producers'
       // half rides along on their matrix steps).  Both roles of a
       // SIMD advance through their MFMAs at the same rate, so starting together they also finish together and the producer's
       // epilogue ran with the matrix pipe idle; this head start for the producer (a "stagger", MI355X_MICROARCH.md "Two waves per
       // SIMD" item 9) puts its epilogue beside the consumer's last MFMAs instead.
-      FP_COPY_OUT_CONS(img, f << 7)
+      FP_COPY_OUT_CONS(img, slice_of(f) << 7)
       FP_SLICE_STEPS(img, f * 12, , false, false, img, 0)
       if (it == 4) FP_STAMP(13)
       __syncthreads();
@@ -547,7 +571,7 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
       const int co = 32 * wq + 16 * i + 4 * g;
       const f32x4 bv = a.bias_b ? *reinterpret_cast<const f32x4*>(a.bias_b + co) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const int q = 16 * j + r;
         *reinterpret_cast<f32x4*>(stage + q * 512 + (((co >> 2) ^ (q & 15)) << 4)) = acc[i][j] + bv;
       }
@@ -581,14 +605,14 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qa[i][ks] = *reinterpret_cast<const bf16x8*>(a.q_w + (size_t)((wave * 3 + i) * 4 + ks) * 512 + lane * 8);
     }
-    f32x4 resv[8];
+    f32x4 resv[NJ];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {                       // the residual rows of all eight passes are requested first
+    for (int k = 0; k < NJ; ++k) {                      // the residual rows of all passes are requested first
       const int row = (tid >> 5) + k * 16, n = n0 + row;
       resv[k] = (row < len_cols && n < len_b) ? *reinterpret_cast<const f32x4*>(a.ln_res + ((size_t)b * a.N + n) * 128 + s * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < NJ; ++k) {
       const int row = (tid >> 5) + k * 16, n = n0 + row;
       const bool inb = row < len_cols, valid = inb && n < len_b;
       const size_t grow = (size_t)b * a.N + n;
@@ -634,7 +658,7 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) qb[i] = *reinterpret_cast<const f32x4*>(a.q_bias + (wave * 3 + i) * 16 + g * 4);
 #pragma unroll 2
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const int row = j * 16 + r;
         bf16x8 xb[4];
 #pragma unroll
@@ -664,10 +688,10 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
     (void)bv;
     const int len_b = a.lens ? a.lens[b] : a.N;
     const unsigned long long seed = a.seed_pre + (a.seed_offset ? *a.seed_offset : 0ull);
-    f32x4 oldv[8], zv[8];
-    float muv[8], rsv[8];
+    f32x4 oldv[NJ], zv[NJ];
+    float muv[NJ], rsv[NJ];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {                       // all global reads of the eight passes first
+    for (int k = 0; k < NJ; ++k) {                      // all global reads of the passes first
       const int row = (tid >> 5) + k * 16, n = n0 + row;
       const bool valid = row < len_cols && n < len_b;
       const size_t grow = (size_t)b * a.N + n;
@@ -678,7 +702,7 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
     }
     f32x4 gw = f32x4{0.f, 0.f, 0.f, 0.f}, gb = gw;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < NJ; ++k) {
       const int row = (tid >> 5) + k * 16, n = n0 + row;
       const bool inb = row < len_cols, valid = inb && n < len_b;
       const size_t grow = (size_t)b * a.N + n;
@@ -710,13 +734,13 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
     }
     if (a.lnb_wt) {                                     // rows this tile does not own (beyond N): zero operands
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < NJ; ++k) {
         const int row = (tid >> 5) + k * 16;
         if (row >= len_cols) *reinterpret_cast<uint2*>(stage + row * 512 + (((s >> 1) ^ (row & 15)) << 4) + ((s & 1) << 3)) = make_uint2(0u, 0u);
       }
     }
     // affine gradients: 16 row groups x 128 channels fold through LDS (behind the staging tile), one atomic per channel per workgroup
-    float* const red = reinterpret_cast<float*>(smem + 128 * 512);
+    float* const red = reinterpret_cast<float*>(smem + NROW * 512);
     *reinterpret_cast<f32x4*>(red + (tid >> 5) * 128 + s * 4) = gw;
     *reinterpret_cast<f32x4*>(red + 2048 + (tid >> 5) * 128 + s * 4) = gb;
     __syncthreads();
@@ -728,27 +752,29 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
       if (t != 0.f) atomicAdd((tid >> 7) ? &a.lnb_db[tid & 127] : &a.lnb_dw[tid & 127], t);
     }
     if (a.lnb_wt) {
-      // DATT = dg1 x W_out: each wave takes 16 rows of the tile (B operand from the 16-bit rows above) against the whole 128 x 128
-      // transposed weight (A operand fragments straight from the pack): 32 MFMAs per wave; (the barrier above ordered the row writes)
-      const int row = wave * 16 + r;
+      // DATT = dg1 x W_out: a wave takes 16 rows of the tile (B operand from the 16-bit rows above) and, with NJ < 8 row blocks, a share of
+      // the 128 output channels of the transposed weight (A operand fragments straight from the pack); (the barrier above ordered the row writes)
+      constexpr int CB = NJ;                             // 16-channel blocks per wave: 8 waves cover NJ row blocks x 8 channel blocks
+      const int rb = wave % NJ, cb0 = (wave / NJ) * CB;
+      const int row = rb * 16 + r;
       bf16x8 xb[4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) xb[ks] = *reinterpret_cast<const bf16x8*>(stage + row * 512 + (((ks * 4 + g) ^ (row & 15)) << 4));
-      f32x4 acc[8];
+      f32x4 acc[CB];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < CB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        bf16x8 wa[8];
+        bf16x8 wa[CB];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(a.lnb_wt + (size_t)(i * 4 + ks) * 512 + lane * 8);
+        for (int i = 0; i < CB; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(a.lnb_wt + (size_t)((cb0 + i) * 4 + ks) * 512 + lane * 8);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = DX_MFMA_H16(wa[i], xb[ks], acc[i]);
+        for (int i = 0; i < CB; ++i) acc[i] = DX_MFMA_H16(wa[i], xb[ks], acc[i]);
       }
       if (row < len_cols) {
-        dx_h16* const orow = a.lnb_datt + ((size_t)b * a.N + n0 + row) * 128 + g * 4;
+        dx_h16* const orow = a.lnb_datt + ((size_t)b * a.N + n0 + row) * 128 + cb0 * 16 + g * 4;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < CB; ++i) {
           bf16x4 o4;
           o4[0] = (dx_h16)acc[i][0]; o4[1] = (dx_h16)acc[i][1]; o4[2] = (dx_h16)acc[i][2]; o4[3] = (dx_h16)acc[i][3];
           *reinterpret_cast<bf16x4*>(orow + i * 16) = o4;
@@ -756,17 +782,17 @@ __global__ __launch_bounds__(512) void ff_pair_kernel(const FFPairArgs a) {
       }
     }
   } else {
-    f32x4 old[8];
+    f32x4 old[NJ];
     if (a.accumulate) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < NJ; ++k) {
         const int u = tid + k * 512;
         const int row = min(u >> 5, len_cols - 1), s = u & 31;
         old[k] = *reinterpret_cast<const f32x4*>(a.Y + ((size_t)b * a.N + n0 + row) * a.ldy + s * 4);
       }
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < NJ; ++k) {
       const int u = tid + k * 512;
       const int row = u >> 5, s = u & 31;
       f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * 512 + ((s ^ (row & 15)) << 4));
@@ -847,17 +873,28 @@ static int ff_pair_launch(const void* X, int ldx, const void* Wa, const void* Wb
 #ifdef DX_FFPAIR_STAMPS
   a.stamps = g_ffpair_stamps;
 #endif
-  const size_t smem = 3 * (size_t)FP_IMG;
   static bool configured = false;
   if (!configured) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_pair_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_pair_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_pair_kernel<true, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP<8>::IMG);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_pair_kernel<false, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP<8>::IMG);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_pair_kernel<true, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP<4>::IMG);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_pair_kernel<false, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP<4>::IMG);
     configured = true;
   }
+  // tile width: 62-token tiles with two workgroups per CU (NJ = 4) or 126-token tiles with one (NJ = 8); DX_FF_NJ overrides (diagnostics)
+  static const int skew_env = getenv("DX_FF_SKEW") ? atoi(getenv("DX_FF_SKEW")) : 0;     // measured neutral (56.5 vs 56.6 us): off
+  a.slice_skew = skew_env;
+  static const int nj_env = getenv("DX_FF_NJ") ? atoi(getenv("DX_FF_NJ")) : 0;
+  const int nj = nj_env == 8 || nj_env == 4 ? nj_env : 8;     // NJ = 4 measured SLOWER (fwd 80-93 vs 56 us, bwd 96-101 vs 68): see FP<NJ>
   hipStream_t s = (hipStream_t)stream;
   dx_prof_begin(DX_PROF_CONV_GEMM, s);
-  if (aux) hipLaunchKernelGGL((ff_pair_kernel<true, false>), dim3(B * dx_cdiv(N, FP_TOK)), dim3(512), smem, s, a);
-  else hipLaunchKernelGGL((ff_pair_kernel<false, true>), dim3(B * dx_cdiv(N, FP_TOK)), dim3(512), smem, s, a);
+  if (nj == 8) {
+    if (aux) hipLaunchKernelGGL((ff_pair_kernel<true, false, 8>), dim3(B * dx_cdiv(N, FP<8>::TOK)), dim3(512), 3 * FP<8>::IMG, s, a);
+    else hipLaunchKernelGGL((ff_pair_kernel<false, true, 8>), dim3(B * dx_cdiv(N, FP<8>::TOK)), dim3(512), 3 * FP<8>::IMG, s, a);
+  } else {
+    if (aux) hipLaunchKernelGGL((ff_pair_kernel<true, false, 4>), dim3(B * dx_cdiv(N, FP<4>::TOK)), dim3(512), 3 * FP<4>::IMG, s, a);
+    else hipLaunchKernelGGL((ff_pair_kernel<false, true, 4>), dim3(B * dx_cdiv(N, FP<4>::TOK)), dim3(512), 3 * FP<4>::IMG, s, a);
+  }
   dx_prof_end(DX_PROF_CONV_GEMM, s);
   DX_LAUNCH_CHECK("dx_ff_pair");
   return DX_OK;

@@ -1152,6 +1152,7 @@ struct WgradJobDev {
 struct WgradBatchArgs {
   WgradJobDev job[WG_MAX_JOBS];
   int ksplit;
+  int xcd_group;   // 1: the tiles of one (job, token slice) pair run on ONE XCD (see the kernel); needs gridDim.x == 8 and gridDim.y * gridDim.z % 8 == 0
 };
 
 __device__ __forceinline__ bf16x8 tr_fragment(const dx_h16* tile, int row0, int col0, int lane) {
@@ -1172,13 +1173,26 @@ __device__ __forceinline__ bf16x8 tr_fragment(const dx_h16* tile, int row0, int 
 // tile).  The wide form puts the same two waves per SIMD on every CU with ONE dY tile per chunk: half the staging per MFMA.
 template <int TAPS, bool DYH, bool XH, int CIW>
 __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel(const WgradBatchArgs ba) {
+  // Workgroup -> (tile, job, token slice).  The 8 tiles of an FFT-block layer share one whole operand (conv1: the 128-channel X, conv2:
+  // the 128-channel dY) and read it chunk by chunk at the same pace.  Dispatched in grid order they sit on 8 DIFFERENT XCDs (blockIdx.x is
+  // the fastest index and workgroups go to the XCDs round-robin), so that operand leaves the memory side eight times (PMC: 2.4x the algorithmic
+  // bytes).  Renumbered, XCD x runs the pairs p = 8 i + x with all 8 tiles of a pair: one fetch per pair, seven L2 hits.
+  int tile_id = blockIdx.x, job_id = blockIdx.y, split_id = blockIdx.z;
+  if (ba.xcd_group) {
+    const int lin = blockIdx.x + 8 * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int xcd = lin & 7, j = lin >> 3;
+    const int pair = (j >> 3) * 8 + xcd;
+    tile_id = j & 7;
+    job_id = pair % (int)gridDim.y;
+    split_id = pair / (int)gridDim.y;
+  }
   WgradBf16Args a;
   {
-    const WgradJobDev& j = ba.job[blockIdx.y];              // kernel-argument memory, wave-uniform index: scalar loads
+    const WgradJobDev& j = ba.job[job_id];                  // kernel-argument memory, wave-uniform index: scalar loads
     a.dY = j.dY; a.ldy = j.ldy; a.dy_bf16 = DYH; a.X = j.X; a.ldx = j.ldx; a.x_bf16 = XH; a.G = j.G;
     a.B = j.B; a.N = j.N; a.Cin = j.Cin; a.Cout = j.Cout; a.ksplit = ba.ksplit; a.lens = j.lens; a.skip_halo = j.skip_halo; a.dbias = j.dbias;
   }
-  if ((int)blockIdx.x >= ((a.Cout + TILE - 1) / TILE) * ((a.Cin + CIW * 32 - 1) / (CIW * 32))) return;   // a job with fewer tiles than the widest
+  if (tile_id >= ((a.Cout + TILE - 1) / TILE) * ((a.Cin + CIW * 32 - 1) / (CIW * 32))) return;   // a job with fewer tiles than the widest
   // wave: 64 co x 32 ci -> 4 x 2 x TAPS MFMA tiles; waves = 2 (co) x CIW (ci).
   // The dY tile and the (halo-extended) X tile are staged once per 64-token chunk and shared by the taps.
   constexpr int PAD = (TAPS - 1) / 2;
@@ -1197,8 +1211,8 @@ __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel
   dx_h16* const Ds = smem_all;
   dx_h16* const Xs = smem_all + WB_BK * WB_LD;
   const int ci_tiles = (a.Cin + CI_T - 1) / CI_T;
-  const int co0 = (blockIdx.x / ci_tiles) * TILE;
-  const int ci0 = (blockIdx.x % ci_tiles) * CI_T;
+  const int co0 = (tile_id / ci_tiles) * TILE;
+  const int ci0 = (tile_id % ci_tiles) * CI_T;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wc = wave / CIW, wt = wave % CIW;
   const int r = lane & 15, g = lane >> 4;
@@ -1284,7 +1298,7 @@ __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel
   for (int i = tid; i < min(a.B, 512); i += NT) limit_s[i] = a.skip_halo >= 0 ? a.lens[i] + a.skip_halo : 0x7fffffff;
   __syncthreads();
   const int step_b = a.ksplit / chunks_per_row, step_k = a.ksplit - step_b * chunks_per_row;
-  int c = blockIdx.z, b = c / chunks_per_row, kc = c - b * chunks_per_row, nc = 0;
+  int c = split_id, b = c / chunks_per_row, kc = c - b * chunks_per_row, nc = 0;
   auto advance = [&]() { c += a.ksplit; b += step_b; kc += step_k; if (kc >= chunks_per_row) { kc -= chunks_per_row; ++b; } };
   auto live = [&]() {
     nc = kc * WB_BK;
@@ -1790,6 +1804,8 @@ int dx_conv_wgrad_batched(const void* jobs_, int njobs, int taps, int dy_bf16, i
   a.ksplit = std::max(1, std::min(min_chunks, dx_cdiv(target, tile_jobs)));
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(tiles, njobs, a.ksplit);
+  static const int grp_env = getenv("DX_WGRAD_XCD_GROUP") ? atoi(getenv("DX_WGRAD_XCD_GROUP")) : 1;
+  a.xcd_group = grp_env && tiles == 8 && (njobs * a.ksplit) % 8 == 0;
   dx_prof_begin(DX_PROF_WGRAD_GEMM, s);
 #define DX_WG_LAUNCH(TAPS_)                                                                                            \
   if (dy_bf16 && x_bf16) hipLaunchKernelGGL((wgrad_bf16_kernel<TAPS_, true, true, 4>), grid, dim3(512), 0, s, a);     \
