@@ -233,11 +233,12 @@ int dx_mel_grad(const float* mel_pred, const float* mel_target, const float* ep,
                 float c_l1, float c_l2, float c_e, int e_per_total, float* dmel, int B, int M, int T, void* stream);
 /* loss.py:85-157 assembled on the device: terms[7] = {speaker_loss, speaker_ce_raw, post_mult_loss, mel_l1, mel_l2, energy, pitch},
  * total[1] = speaker + post_mult + l1 + l2 + ecw * energy + pcw * pitch; d_spk = dlogits * w; d_pm = pmw * pm / ||pm||_2.
- * w = *spk_w_dev if given (device scalar, re-read by every replay of a captured graph) else spk_w.  NULL ce / pm / esum / psum: term off. */
+ * w = *spk_w_dev if given (device scalar, re-read by every replay of a captured graph) else spk_w.  NULL ce / pm / esum / psum: term off.
+ * grad_scale multiplies d_spk and d_pm (not the terms): the factor d(total)/d(what the caller differentiates), e.g. loss scale / accumulation steps. */
 int dx_loss_finalize(const float* ce, const float* spk_w_dev, float spk_w, const float* dlogits, float* d_spk, int n_logits,
                      const float* pm, float* d_pm, int n_pm, float pmw,
                      const float* l1sum, const float* l2sum, const int* lens, int B, int M, float msw,
-                     const float* esum, float ecw, const float* psum, float pcw, float* terms, float* total, void* stream);
+                     const float* esum, float ecw, const float* psum, float pcw, float* terms, float* total, float grad_scale, void* stream);
 int dx_pitch_mse(const float* pp, int ldp, const float* gt, const int* lens, float* sums, int B, int T, void* stream);   /* ldp / ldd: element stride between consecutive frames of pp / dpp (the predictor's last conv writes 4-wide rows, channel 0 is the prediction) */
 int dx_pitch_grad(const float* pp, int ldp, const float* gt, const int* lens, const float* sums, float scale, float* dpp, int ldd, int B, int T, void* stream);
 

@@ -38,15 +38,39 @@ def main():
     dll.dx_ff_pair_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
     P = lambda t: ctypes.c_void_p(None if t is None else t.data_ptr())
     wa, wb = (i2.bwd, i1.bwd) if backward else (i1.fwd, i2.fwd)
+    mode = os.environ.get('DX_STAMP_MODE', 'pair')     # pair | ln | lnqkv (forward forms) | block (the whole feed-forward half of the backward)
+    S = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ln_w, ln_b, film, res = torch.ones(D, device=dev), torch.zeros(D, device=dev), rn(B, 2 * D), rn(B, N, D)
+    z, yln, mean, rstd = torch.empty(B, N, D, device=dev), torch.empty(B, N, D, device=dev), torch.empty(B, N, device=dev), torch.empty(B, N, device=dev)
+    win, bq = rn(3 * D, D, sc=1 / math.sqrt(D)), rn(3 * D, sc=0.1)
+    pq = ops.PackedWeight(win).image('bf16')
+    qkv = torch.empty(B, N, 3 * D, dtype=torch.bfloat16, device=dev)
+    pout = ops.PackedWeight(rn(D, D, sc=1 / math.sqrt(D))).image('bf16')
+    dg1, dg2, datt = (torch.empty(B, N, D, dtype=torch.bfloat16, device=dev) for _ in range(3))
+    acc = torch.zeros(4, D, device=dev)
+    dfilm = torch.zeros(B, 2 * D, device=dev)
+    z1, mean1, rstd1, dy2 = rn(B, N, D), rn(B, N), rn(B, N).abs() + 0.5, rn(B, N, D) * valid
+    F32 = ctypes.c_float
     for _ in range(3):
-        rc = dll.dx_ff_pair(P(x), 128, P(wa), P(wb), P(None if backward else b1), P(None if backward else b2), P(aux), Fc, P(h), Fc, P(y), 128,
-                            B, N, Fc, int(not backward), int(backward), P(lens), 1, P(None), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if mode == 'pair':
+            rc = dll.dx_ff_pair(P(x), 128, P(wa), P(wb), P(None if backward else b1), P(None if backward else b2), P(aux), Fc, P(h), Fc, P(y), 128,
+                                B, N, Fc, int(not backward), int(backward), P(lens), 1, P(None), S)
+        elif mode in ('ln', 'lnqkv'):
+            args = [P(x), 128, P(i1.fwd), P(i2.fwd), P(b1), P(b2), P(h), Fc, P(z), B, N, Fc, P(lens), 1, P(None), P(res), P(ln_w), P(ln_b), P(film), 2 * D,
+                    P(yln), P(mean), P(rstd), ctypes.c_uint64(5), F32(0.1), P(None)]
+            rc = dll.dx_ff_pair_ln(*args, S) if mode == 'ln' else dll.dx_ff_pair_ln_qkv(*args, P(pq.fwd), P(bq), P(qkv), S)
+        else:
+            aux_b = aux if aux is not None else ops.conv_gemm(x, p1, b1, relu=True, lens=lens, halo=1, out_dtype=torch.bfloat16)
+            rc = dll.dx_ff_block_bwd(P(dy2), P(z1), P(mean1), P(rstd1), P(ln_w), P(ln_b), P(film), 2 * D, P(dg2), P(acc[0]), P(acc[1]), P(dfilm), 2 * D,
+                                     ctypes.c_uint64(5), F32(0.1), P(i2.bwd), P(i1.bwd), P(aux_b), Fc, P(h), Fc, P(y), B, N, Fc, P(lens), 1,
+                                     P(z1), P(mean1), P(rstd1), P(ln_w), P(ln_b), P(dg1), P(acc[2]), P(acc[3]), ctypes.c_uint64(6), F32(0.1),
+                                     P(pout.bwd), P(datt), P(None), S)
         assert rc == 0
     torch.cuda.synchronize()
     st = stamps.cpu()
     live = st[:, 0, 15] > 0
     st = st[live & (st[:, 0, 3] > 0)]                        # workgroups that ran the slice loop
-    print(f'{"bwd" if backward else "fwd"}: {st.shape[0]} live workgroups of {nwg}')
+    print(f'{mode} {"bwd" if backward else "fwd"}: {st.shape[0]} live workgroups of {nwg}')
     names = ['tile search', 'stage x + first weight loads'] + [f'iteration {i}' for i in range(9)] + ['final epilogue']
     idx = [0, 1, 2] + [3 + i for i in range(9)] + [15]
     for role, rname in ((0, 'producer'), (1, 'consumer')):

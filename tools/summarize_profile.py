@@ -67,12 +67,25 @@ def label_of(kernel_name):
 
 
 def stats(d, steps, out, table_json=None, pmc_json=None):
-    rows = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
+    """``steps`` is only a fallback.  The trace is cut to WHOLE STEPS: everything after the first ``adam_kernel`` launch up to and including the
+    last one (a step ends with the fused Adam + the one-launch re-pack that follows it, which is attributed to the next window: the same count
+    per step either way).  Round 2 divided the whole trace by the step count, so the ~1,600 device-to-device copies of model SETUP
+    (load_state_dict, optimiser re-homing) appeared as "62 copyBuffer launches per step"."""
     with open(_find(d, 'kernel_trace.csv')) as f:
-        for r in csv.DictReader(f):
-            dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-            e = rows[demangle(r['Kernel_Name'])]
-            e[0] += 1; e[1] += dur; e[2] = min(e[2], dur); e[3] = max(e[3], dur)
+        trace = sorted(csv.DictReader(f), key=lambda r: int(r['Start_Timestamp']))
+    adam = [i for i, r in enumerate(trace) if 'adam_kernel' in r['Kernel_Name']]
+    if len(adam) >= 2:
+        trace, steps = trace[adam[0] + 1:adam[-1] + 1], len(adam) - 1
+    rows = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
+    for r in trace:
+        dur = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+        e = rows[demangle(r['Kernel_Name'])]
+        e[0] += 1; e[1] += dur; e[2] = min(e[2], dur); e[3] = max(e[3], dur)
+    if trace:
+        span = (int(trace[-1]['End_Timestamp']) - int(trace[0]['Start_Timestamp'])) / 1e6
+        busy = sum(e[1] for e in rows.values()) / 1e3
+        print('steady-state window: %d steps, %.3f ms per step wall, %.3f ms per step inside kernels (%.1f %% of the wall: the rest is gaps between launches)'
+              % (steps, span / steps, busy / steps, 100 * busy / span))
     total = sum(e[1] for e in rows.values())
     table = json.load(open(table_json))['kernels'] if table_json else {}
     precision = json.load(open(table_json))['precision'] if table_json else 'bf16'

@@ -139,16 +139,17 @@ struct LossFinalizeArgs {
   const float* l1sum; const float* l2sum; const int* lens; int B; int M; float msw;
   const float* esum; float ecw; const float* psum; float pcw;
   float* terms; float* total;
+  float grad_scale;   // the two small gradients leave multiplied by it (a trainer's loss scale / accumulation factor); terms and total do not
 };
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const LossFinalizeArgs a) {
   __shared__ float scratch[4];
   const int tid = threadIdx.x;
   const float w = a.spk_w_dev ? *a.spk_w_dev : a.spk_w;
-  for (int i = tid; i < a.n_logits; i += 256) a.d_spk[i] = a.dlogits[i] * w;
+  for (int i = tid; i < a.n_logits; i += 256) a.d_spk[i] = a.dlogits[i] * (w * a.grad_scale);
   float sq = 0.f;
   for (int i = tid; i < a.n_pm; i += 256) sq += a.pm[i] * a.pm[i];
   const float nrm = sqrtf(block_sum_256(sq, scratch));
-  for (int i = tid; i < a.n_pm; i += 256) a.d_pm[i] = a.pmw * a.pm[i] / nrm;
+  for (int i = tid; i < a.n_pm; i += 256) a.d_pm[i] = a.grad_scale * a.pmw * a.pm[i] / nrm;
   float l1 = 0.f, l2 = 0.f, n = 0.f;
   for (int i = tid; i < a.B; i += 256) {
     const float len = (float)a.lens[i], d = (float)a.M * len;
@@ -201,11 +202,11 @@ int dx_mel_grad(const float* mel_pred, const float* mel_target, const float* ep,
 int dx_loss_finalize(const float* ce, const float* spk_w_dev, float spk_w, const float* dlogits, float* d_spk, int n_logits,
                      const float* pm, float* d_pm, int n_pm, float pmw,
                      const float* l1sum, const float* l2sum, const int* lens, int B, int M, float msw,
-                     const float* esum, float ecw, const float* psum, float pcw, float* terms, float* total, void* stream) {
+                     const float* esum, float ecw, const float* psum, float pcw, float* terms, float* total, float grad_scale, void* stream) {
   DX_REQUIRE(l1sum && l2sum && lens && terms && total && B > 0 && M > 0, "dx_loss_finalize: bad arguments");
   DX_REQUIRE(n_logits == 0 || (dlogits && d_spk && ce), "dx_loss_finalize: speaker term needs ce, dlogits, d_spk");
   DX_REQUIRE(n_pm == 0 || (pm && d_pm), "dx_loss_finalize: post-multiplier term needs pm, d_pm");
-  LossFinalizeArgs a{ce, spk_w_dev, spk_w, dlogits, d_spk, n_logits, pm, d_pm, n_pm, pmw, l1sum, l2sum, lens, B, M, msw, esum, ecw, psum, pcw, terms, total};
+  LossFinalizeArgs a{ce, spk_w_dev, spk_w, dlogits, d_spk, n_logits, pm, d_pm, n_pm, pmw, l1sum, l2sum, lens, B, M, msw, esum, ecw, psum, pcw, terms, total, grad_scale};
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
   DX_LAUNCH_CHECK("dx_loss_finalize");
   return DX_OK;

@@ -91,8 +91,12 @@ class _LossFn(torch.autograd.Function):
             des, esum = ops.energy_diff(ep, et, lens.i32, arena=arena)
         # energy term: ecw / (sum of valid lengths), the division done on the device (nothing host-side is frozen into a graph)
         need_grad = cfg.get('need_grad', True)       # False under no_grad (Trainer.validate): the terms only, none of the gradient launches
-        dmel = ops.mel_grad(mel_pred, mel_target, ep, des, lens.i32, cfg['msw'] / (M * B), cfg['msw'] / (M * B), cfg['ecw'] if des is not None else 0.0,
-                            e_per_total=True) if need_grad else None
+        # ``grad_scale``: d(what the caller differentiates) / d(total), known up front (a trainer: loss scale / accumulation steps).  Every
+        # gradient produced here is multiplied by it on the way out and ``backward`` then hands them on as they are: no ``total * c`` launch,
+        # no three ``* g_total`` launches (one of them a 14 MB read-modify-write of the mel gradient).
+        gs = float(cfg.get('grad_scale', 1.0))
+        dmel = ops.mel_grad(mel_pred, mel_target, ep, des, lens.i32, gs * cfg['msw'] / (M * B), gs * cfg['msw'] / (M * B),
+                            gs * cfg['ecw'] if des is not None else 0.0, e_per_total=True) if need_grad else None
         psum = None
         if pitch_layers is not None and frames_pitch is not None and cfg['pcw'] > 0:
             # frozen predictor on the predicted mel, channels-last; gradient flows through it to the mel only
@@ -110,7 +114,7 @@ class _LossFn(torch.autograd.Function):
             frames_pitch = frames_pitch.contiguous()
             psum = ops.pitch_mse(pp, frames_pitch, lens.i32, arena=arena)                          # (read and written in place: no slice copies)
             if need_grad:
-                g = ops.pitch_grad(pp, frames_pitch, lens.i32, psum, cfg['pcw'], out=ops._zeros(arena, B, T, 4, device=dev))
+                g = ops.pitch_grad(pp, frames_pitch, lens.i32, psum, gs * cfg['pcw'], out=ops._zeros(arena, B, T, 4, device=dev))
                 # each input-gradient GEMM applies the previous layer's BatchNorm scale and ReLU mask in its epilogue
                 for k in range(len(pitch_layers) - 1, 0, -1):
                     prev = pitch_layers[k - 1]
@@ -120,11 +124,12 @@ class _LossFn(torch.autograd.Function):
                 dmel = ops.transpose(d, add_to=dmel)                                   # dmel is this function's own fresh tensor
         # the seven terms, the total and the two small gradients: one launch (was ~30 one-element ATen launches)
         terms, total, d_spk, d_pm = ops.loss_finalize(ce, dlogits, cfg['spk_weight'], pm, cfg['pmw'], sums, lens.i32, M, cfg['msw'],
-                                                      esum, cfg['ecw'], psum, cfg['pcw'])
+                                                      esum, cfg['ecw'], psum, cfg['pcw'], grad_scale=gs)
         if d_pm is not None:
             d_pm = d_pm.view_as(post_multipliers)
         if need_grad:
             ctx.save_for_backward(dmel, d_spk, d_pm)
+        ctx.prescaled = 'grad_scale' in cfg
         ctx.mark_non_differentiable(terms)
         ctx.set_materialize_grads(False)
         return total, terms
@@ -132,6 +137,8 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, _g_terms):
         dmel, d_spk, d_pm = ctx.saved_tensors
+        if ctx.prescaled:                          # the caller's factor is already inside (and g_total is its constant 1)
+            return (dmel, d_spk, d_pm, None, None, None, None, None, None, None)
         return (dmel * g_total, None if d_spk is None else d_spk * g_total, None if d_pm is None else d_pm * g_total,
                 None, None, None, None, None, None, None)
 
@@ -148,6 +155,9 @@ class DaftExprtLoss(nn.Module):
         self.energy_consistency_weight = getattr(hparams, 'energy_consistency_weight', 0.0)
         self.pitch_consistency_weight = getattr(hparams, 'pitch_consistency_weight', 0.0)
         self.pitch_layers = None
+        # None: ``backward`` multiplies by the incoming gradient, as autograd expects.  A float (set by trainer.Trainer): the loss's gradients
+        # are produced pre-multiplied by it and the trainer calls ``loss.backward(gradient=1)``
+        self.grad_scale = None
         self.runtime = ops.Runtime(ops.DEFAULT.precision)     # this object's own execution state (see ops.Runtime)
         pp_path = getattr(hparams, 'pitch_predictor_path', '')
         if self.pitch_consistency_weight > 0 and pp_path:
@@ -178,12 +188,15 @@ class DaftExprtLoss(nn.Module):
         mel_preds, output_lengths = decoder_preds
         if not mel_preds.is_cuda:
             raise RuntimeError('DaftExprtLoss (MI355X build) runs on the GPU only; there is no CPU path')
-        lens = output_lengths if isinstance(output_lengths, Lengths) else Lengths(output_lengths, host=getattr(output_lengths, '_dx_host_lengths', None))
+        lens = output_lengths if isinstance(output_lengths, Lengths) else getattr(output_lengths, '_dx_lengths', None)
+        if lens is None or lens.i64 is not output_lengths:     # (the model leaves its Lengths object on the tensor it returns)
+            lens = Lengths(output_lengths, host=getattr(output_lengths, '_dx_host_lengths', None))
         pm = post_multipliers if (self.post_mult_weight != 0.0 and torch.is_tensor(post_multipliers)) else None
         # ``iteration``: the step number, or -- from a trainer that replays captured graphs -- the adversarial weight itself as a
         # device scalar it updates before every replay
         spk_weight = iteration if torch.is_tensor(iteration) else self.update_adversarial_weight(iteration)
         cfg = {'need_grad': torch.is_grad_enabled() and mel_preds.requires_grad,
+               **({'grad_scale': self.grad_scale} if self.grad_scale is not None else {}),
                'spk_weight': spk_weight, 'pmw': self.post_mult_weight, 'msw': self.mel_spec_weight,
                'ecw': self.energy_consistency_weight, 'pcw': self.pitch_consistency_weight if self.pitch_layers is not None else 0.0}
         total, terms = _LossFn.apply(mel_preds, speaker_preds, pm, mel_targets, speaker_ids, frames_pitch, lens, cfg, self.pitch_layers, self.runtime)

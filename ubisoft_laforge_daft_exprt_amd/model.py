@@ -427,7 +427,14 @@ class DaftExprt(nn.Module):
 
     @staticmethod
     def _lengths(t):
-        return Lengths(t, host=getattr(t, '_dx_host_lengths', None))
+        """A fresh ``Lengths`` per forward call (never reused across calls: the tensor's contents may have changed), left on the tensor
+        object so that the loss, which is handed the same output-length tensor, does not build a second one (an int64 -> int32 launch)."""
+        obj = Lengths(t, host=getattr(t, '_dx_host_lengths', None))
+        try:
+            t._dx_lengths = obj
+        except AttributeError:
+            pass
+        return obj
 
     @staticmethod
     def _require_gpu(t):

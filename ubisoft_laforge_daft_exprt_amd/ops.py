@@ -790,7 +790,7 @@ def mel_grad(mel_pred, mel_target, ep, des, lens, c_l1, c_l2, c_e, e_per_total=F
     return dmel
 
 
-def loss_finalize(ce, dlogits, spk_w, pm, pmw, sums, lens, M, msw, esum, ecw, psum, pcw):
+def loss_finalize(ce, dlogits, spk_w, pm, pmw, sums, lens, M, msw, esum, ecw, psum, pcw, grad_scale=1.0):
     """-> (terms[7], total[1], d_spk or None, d_pm or None); ``spk_w``: python float or device scalar tensor"""
     dev = sums.device
     B = sums.shape[1]
@@ -800,7 +800,7 @@ def loss_finalize(ce, dlogits, spk_w, pm, pmw, sums, lens, M, msw, esum, ecw, ps
     w_dev = spk_w if torch.is_tensor(spk_w) else None
     lib().dx_loss_finalize(_p(ce), _p(w_dev), 0.0 if w_dev is not None else float(spk_w), _p(dlogits), _p(d_spk), 0 if dlogits is None else dlogits.numel(),
                            _p(pm), _p(d_pm), 0 if pm is None else pm.numel(), float(pmw), _p(sums[0]), _p(sums[1]), _p(lens), B, M, float(msw),
-                           _p(esum), float(ecw), _p(psum), float(pcw), _p(out), _p(out[7:]), _stream())
+                           _p(esum), float(ecw), _p(psum), float(pcw), _p(out), _p(out[7:]), float(grad_scale), _stream())
     return out[:7], out[7], d_spk, d_pm
 
 

@@ -97,6 +97,7 @@ class Trainer:
         self._conditioner_generation = getattr(conditioner, 'generation', None)
         self.adv_weight = torch.zeros((), dtype=torch.float32, device=self.device)    # read by the captured loss
         self.val_adv_weight = torch.zeros((), dtype=torch.float32, device=self.device)   # validation: iteration = 0 (train.py:198)
+        self._one = torch.ones((), dtype=torch.float32, device=self.device)
         if model.runtime.seed_offset is None:
             model.runtime.seed_offset = torch.zeros((), dtype=torch.int64, device=self.device)
         self.optimizer = FusedAdam(self.reducer, lr=hparams.initial_learning_rate, betas=hparams.betas, eps=hparams.epsilon,
@@ -150,16 +151,19 @@ class Trainer:
         ops.begin_step_arena(self.criterion.runtime, self.device)
         rt.backward_split, rt.cut_levels = [], self.cut_levels
         tot, terms = None, []
+        # d(what is differentiated) / d(loss) = loss scale / accumulation steps is folded into the loss kernels' own gradient outputs
+        self.criterion.grad_scale = self.loss_scale / k
         try:
             for inputs, targets in parsed:
                 loss, indiv = self._forward_loss(inputs, targets, iteration)
                 with red.accumulate(sync=False):                 # the exchange is launched explicitly, group by group
-                    (loss * (self.loss_scale / k)).backward()
+                    loss.backward(gradient=self._one)
                 part = loss.detach() / k if k != 1 else loss.detach()
                 tot = part if tot is None else tot + part
                 terms.append(indiv)
         finally:
             cuts, rt.backward_split = rt.backward_split, None
+            self.criterion.grad_scale = None
         ops.flush_wgrads(rt)                         # the FFT blocks' queued weight gradients, 8 layers per launch
 
         def end_arenas():
