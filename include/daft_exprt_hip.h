@@ -105,11 +105,15 @@ int dx_ff_pair(const void* X, int ldx, const void* Wa, const void* Wb, const flo
  * film / seeds as in dx_ln_fwd with C = 128 and halo 0 (rows >= lens[b] are masked); lens is required; skip_halo as in dx_ff_pair (it
  * only decides which whole tiles are computed: the hidden rows of the halo are still written to H for the weight gradients). */
 /* H may be NULL in the forward entry points (dx_ff_pair with relu_mid, dx_ff_pair_ln, dx_ff_pair_ln_qkv): the mid activation is then not
- * written (inference: nothing reads it; 2 KB per token saved). */
+ * written (inference: nothing reads it; 2 KB per token saved).
+ * hmask (optional; dx_ff_pair_ln / dx_ff_pair_ln_qkv write it, dx_ff_block_bwd reads it INSTEAD of aux for the ReLU gradient): the sign of
+ * the hidden activation, one bit per element, as uint32 [B * ceil(N / 126)][F / 128][4][2][64] -- the kernel's own register layout, one
+ * coalesced dword per lane (128 B per token instead of re-reading 2 KB of H with 8-byte strided loads in the backward's producer epilogue;
+ * model.py:213 ReLU backward).  Forward and backward must use the same tile width (they do: both default to 126-token tiles). */
 int dx_ff_pair_ln(const void* X, int ldx, const void* Wa, const void* Wb, const float* bias_a, const float* bias_b, void* H, int ldh, float* Z,
                   int B, int N, int F, const int* lens, int skip_halo, const int* rows_exist,
                   const float* res, const float* ln_w, const float* ln_b, const float* film, int ld_film, float* Yln, float* mean, float* rstd,
-                  uint64_t seed_pre, float p_pre, const uint64_t* seed_offset, void* stream);
+                  uint64_t seed_pre, float p_pre, const uint64_t* seed_offset, void* hmask, void* stream);
 /* dx_ff_pair_ln followed, on the same tile, by the NEXT FFT block's attention in-projection (model.py:163-171, F.multi_head_attention_forward's
  * linear(x, in_proj_weight, in_proj_bias)): QKV (16-bit [B][N][384]) = Yln x Wq^T + bias_q, what dx_conv_gemm(Yln, Wq, bias_q, taps = 1,
  * lens, skip_halo = 0, y 16-bit) writes (rows >= lens[b] of a live tile = the bias; tiles beyond the halo = 0).  Wq: the forward pack of
@@ -117,7 +121,7 @@ int dx_ff_pair_ln(const void* X, int ldx, const void* Wa, const void* Wb, const 
 int dx_ff_pair_ln_qkv(const void* X, int ldx, const void* Wa, const void* Wb, const float* bias_a, const float* bias_b, void* H, int ldh, float* Z,
                       int B, int N, int F, const int* lens, int skip_halo, const int* rows_exist,
                       const float* res, const float* ln_w, const float* ln_b, const float* film, int ld_film, float* Yln, float* mean, float* rstd,
-                      uint64_t seed_pre, float p_pre, const uint64_t* seed_offset, const void* Wq, const float* bias_q, void* QKV, void* stream);
+                      uint64_t seed_pre, float p_pre, const uint64_t* seed_offset, const void* Wq, const float* bias_q, void* QKV, void* hmask, void* stream);
 /* dx_ff_pair (input-gradient pair, accumulate = 1) with the BACKWARD of the block's first LayerNorm folded into its epilogue: Y holds the
  * residual-branch gradient on entry and dz1 = LayerNorm-backward(Y + pair result) on return; DG (16-bit [B][N][128]) = dropout(dz1), the
  * operand of the out-projection's backward GEMMs; dw / db (caller-initialised [128]) accumulate the affine gradients.  z / mean / rstd /
@@ -139,7 +143,7 @@ int dx_ff_block_bwd(const float* dY2, const float* z2, const float* mean2, const
                     const void* Wa, const void* Wb, const void* aux, int ld_aux, void* H, int ldh, float* Y,
                     int B, int N, int F, const int* lens, int skip_halo,
                     const float* z1, const float* mean1, const float* rstd1, const float* ln1_w, const float* ln1_b, void* DG1, float* dw1, float* db1,
-                    uint64_t seed1, float p1, const void* Wout_bwd, void* DATT, const uint64_t* seed_offset, void* stream);
+                    uint64_t seed1, float p1, const void* Wout_bwd, void* DATT, const uint64_t* seed_offset, const void* hmask, void* stream);
 /* out[c] += sum_rows X[row][c]   (bias gradients) */
 int dx_colsum(const void* X, int ldx, float* out, long rows, int C, int x_bf16, void* stream);
 

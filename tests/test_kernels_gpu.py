@@ -494,6 +494,42 @@ def test_ff_block_backward_equals_three_launches(ops, precision, p_drop, use_fil
         ops.set_precision('f32')
 
 
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+def test_ff_block_backward_with_sign_words_equals_the_stored_activation(ops, precision):
+    """The backward's ReLU mask from the forward's sign words (``hmask``: one bit per hidden element in the kernel's register layout) is the
+    mask ``h > 0`` it replaces: same hidden gradient, same dz1, bit for bit; utterances on tile edges, on the halo row, inside a tile and
+    longer than one tile."""
+    ops.set_precision(precision)
+    try:
+        h16 = ops.hidden_dtype()
+        B, N, Fc = 6, 300, 1024
+        lens = lens_tensor([300, 252, 126, 127, 40, 1])
+        valid = (torch.arange(N, device=DEV)[None, :] < lens[:, None])
+        vf = valid[:, :, None].float()
+        w1 = randn(Fc, 128, 3, seed=2, scale=1 / math.sqrt(384))
+        w2 = randn(128, Fc, 3, seed=4, scale=1 / math.sqrt(3 * Fc))
+        b1, b2 = randn(Fc, seed=3, scale=0.1), randn(128, seed=33, scale=0.1)
+        p1, p2 = ops.PackedWeight(w1), ops.PackedWeight(w2)
+        x = (randn(B, N, 128, seed=1) * vf).to(h16)
+        res = randn(B, N, 128, seed=14) * vf
+        l2w, l2b = 1 + 0.1 * randn(128, seed=8), randn(128, seed=9, scale=0.1)
+        l1w, l1b = 1 + 0.1 * randn(128, seed=10), randn(128, seed=11, scale=0.1)
+        film = randn(B, 256, seed=12)
+        z2, h, _, m2, r2, mask = ops.ff_pair_ln(x, p1, p2, b1, b2, lens, res, l2w, l2b, film, want_mask=True)
+        assert mask is not None and mask.dtype == torch.int32
+        dy2 = randn(B, N, 128, seed=5) * vf
+        z1 = randn(B, N, 128, seed=7)
+        m1, r1 = z1.mean(dim=2), 1.0 / torch.sqrt(z1.var(dim=2, unbiased=False) + 1e-5)
+        po = ops.PackedWeight(randn(128, 128, seed=13, scale=0.09))
+        kw = dict(seed2=71, p2=0.0, seed1=72, p1=0.0, out_pack=po)
+        a = ops.ff_block_bwd(dy2, z2, m2, r2, l2w, l2b, film, p1, p2, lens, h, z1, m1, r1, l1w, l1b, **kw)
+        b = ops.ff_block_bwd(dy2, z2, m2, r2, l2w, l2b, film, p1, p2, lens, h, z1, m1, r1, l1w, l1b, hmask=mask, **kw)
+        assert torch.equal(a[1], b[1]), float((a[1].float() - b[1].float()).abs().max())     # the hidden gradient
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[9], b[9])
+    finally:
+        ops.set_precision('f32')
+
+
 @pytest.mark.parametrize('precision', ['f32', 'bf16', 'fp16'])
 def test_channel_affine_vs_torch(ops, precision):
     """dx_channel_affine (eval-mode BatchNorm of the frozen pitch predictor, layers/pitch_predictor.py:49-62) in fp32 and in the 16-bit

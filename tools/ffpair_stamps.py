@@ -51,6 +51,9 @@ def main():
     dfilm = torch.zeros(B, 2 * D, device=dev)
     z1, mean1, rstd1, dy2 = rn(B, N, D), rn(B, N), rn(B, N).abs() + 0.5, rn(B, N, D) * valid
     F32 = ctypes.c_float
+    hmask = torch.zeros(B * ((N + 125) // 126), Fc // 128, 4, 2, 64, dtype=torch.int32, device=dev)
+    if mode == 'block':                                  # real sign words from a forward run of the product library
+        hmask = ops.ff_pair_ln(x, p1, p2, b1, b2, lens, res, ln_w, ln_b, film, want_mask=True)[-1]
     for _ in range(3):
         if mode == 'pair':
             rc = dll.dx_ff_pair(P(x), 128, P(wa), P(wb), P(None if backward else b1), P(None if backward else b2), P(aux), Fc, P(h), Fc, P(y), 128,
@@ -58,13 +61,13 @@ def main():
         elif mode in ('ln', 'lnqkv'):
             args = [P(x), 128, P(i1.fwd), P(i2.fwd), P(b1), P(b2), P(h), Fc, P(z), B, N, Fc, P(lens), 1, P(None), P(res), P(ln_w), P(ln_b), P(film), 2 * D,
                     P(yln), P(mean), P(rstd), ctypes.c_uint64(5), F32(0.1), P(None)]
-            rc = dll.dx_ff_pair_ln(*args, S) if mode == 'ln' else dll.dx_ff_pair_ln_qkv(*args, P(pq.fwd), P(bq), P(qkv), S)
+            rc = dll.dx_ff_pair_ln(*args, P(hmask), S) if mode == 'ln' else dll.dx_ff_pair_ln_qkv(*args, P(pq.fwd), P(bq), P(qkv), P(hmask), S)
         else:
             aux_b = aux if aux is not None else ops.conv_gemm(x, p1, b1, relu=True, lens=lens, halo=1, out_dtype=torch.bfloat16)
             rc = dll.dx_ff_block_bwd(P(dy2), P(z1), P(mean1), P(rstd1), P(ln_w), P(ln_b), P(film), 2 * D, P(dg2), P(acc[0]), P(acc[1]), P(dfilm), 2 * D,
                                      ctypes.c_uint64(5), F32(0.1), P(i2.bwd), P(i1.bwd), P(aux_b), Fc, P(h), Fc, P(y), B, N, Fc, P(lens), 1,
                                      P(z1), P(mean1), P(rstd1), P(ln_w), P(ln_b), P(dg1), P(acc[2]), P(acc[3]), ctypes.c_uint64(6), F32(0.1),
-                                     P(pout.bwd), P(datt), P(None), S)
+                                     P(pout.bwd), P(datt), P(None), P(hmask if os.environ.get('DX_STAMP_MASK', '1') != '0' else None), S)
         assert rc == 0
     torch.cuda.synchronize()
     st = stamps.cpu()

@@ -60,13 +60,16 @@ def main():
     res = rn(B, N, D)
     rows.append(('fwd + LN epilogue', timeit(lambda: ops.ff_pair_ln(x, p1, p2, b1, b2, lens, res, ln_w, ln_b, film, seed_pre=5, p_pre=0.1))))
     rows.append(('fwd + LN + next qkv', timeit(lambda: ops.ff_pair_ln(x, p1, p2, b1, b2, lens, res, ln_w, ln_b, film, seed_pre=5, p_pre=0.1, next_in=(pin, bin_)))))
-    z2, _, _, mean2, rstd2 = ops.ff_pair_ln(x, p1, p2, b1, b2, lens, res, ln_w, ln_b, film, seed_pre=5, p_pre=0.1)
+    z2, _, _, mean2, rstd2, hmask = ops.ff_pair_ln(x, p1, p2, b1, b2, lens, res, ln_w, ln_b, film, seed_pre=5, p_pre=0.1, want_mask=True)
+    rows.append(('fwd + LN + mask out', timeit(lambda: ops.ff_pair_ln(x, p1, p2, b1, b2, lens, res, ln_w, ln_b, film, seed_pre=5, p_pre=0.1, want_mask=True))))
     z1, mean1, rstd1 = rn(B, N, D), rn(B, N), rn(B, N).abs() + 0.5
     dy2 = rn(B, N, D) * valid
     rows.append(('block bwd (LN2b+pair+LN1b)', timeit(lambda: ops.ff_block_bwd(dy2, z2, mean2, rstd2, ln_w, ln_b, film, p1, p2, lens, h, z1, mean1, rstd1, ln_w, ln_b,
                                                                                seed2=5, p2=0.1, seed1=6, p1=0.1))))
     rows.append(('block bwd + datt', timeit(lambda: ops.ff_block_bwd(dy2, z2, mean2, rstd2, ln_w, ln_b, film, p1, p2, lens, h, z1, mean1, rstd1, ln_w, ln_b,
                                                                      seed2=5, p2=0.1, seed1=6, p1=0.1, out_pack=pout))))
+    rows.append(('block bwd + datt, sign words', timeit(lambda: ops.ff_block_bwd(dy2, z2, mean2, rstd2, ln_w, ln_b, film, p1, p2, lens, h, z1, mean1, rstd1, ln_w, ln_b,
+                                                                                 seed2=5, p2=0.1, seed1=6, p1=0.1, out_pack=pout, hmask=hmask))))
     for name, us in rows:
         print(f'{axis}-level B={B} N={N} valid tokens={tokens}: {name:28s} {us:8.1f} us   {flops / us / 1e6:7.1f} TFLOP/s algorithmic '
               f'({100 * flops / us / 1e6 / 2500:.1f} % of 2.5 PF)')

@@ -90,6 +90,9 @@ struct FFPairArgs {
   const float* lnp_film; int lnp_ld_film;
   dx_h16* lnp_dg; float* lnp_dw; float* lnp_db; float* lnp_dfilm; int lnp_ld_dfilm;
   unsigned long long lnp_seed; unsigned lnp_thresh; float lnp_inv_keep;
+  // optional ReLU-sign words (forward: written; backward: read INSTEAD of aux): one dword per lane, slice and 16-channel block, bit k of it =
+  // "hidden value (column tile j = NJ-1 - k/4, channel 3 - k%4 of the lane's four) was > 0"; [B * tiles][F / 128][4 waves][2][64 lanes]
+  unsigned* hmask;
   int slice_skew;                    // 1: workgroup w starts its walk over the hidden slices at slice w % nslices (see the kernel)
   unsigned long long* stamps;        // diagnostic builds (-DDX_FFPAIR_STAMPS, tools/ffpair_stamps.py) only: [workgroup][role][16] s_memtime values
 };
@@ -131,7 +134,9 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 #define FP_MMA(W, X, C) C = DX_MFMA_H16(__builtin_bit_cast(bf16x8, W), __builtin_bit_cast(bf16x8, X), C);
 
 // AUX: backward (mid = sign mask of the stored forward activation); RELU: forward (mid = ReLU)
-template <bool AUX, bool RELU, int NJ>
+// MASK (backward only): the ReLU gradient mask comes from the forward's sign words (a.hmask) instead of the stored activation (a.aux) --
+// a compile-time choice: with both paths in one kernel the aux prefetch registers stay allocated and the kernel spills
+template <bool AUX, bool RELU, int NJ, bool MASK = false>
 __global__ __launch_bounds__(512, NJ == 8 ? 2 : 4) void ff_pair_kernel(const FFPairArgs a) {
   constexpr int FP_TOK = FP<NJ>::TOK, FP_HR = FP<NJ>::HR, FP_IMG = FP<NJ>::IMG, NROW = FP<NJ>::NROW, XP = FP<NJ>::XP, RP = FP<NJ>::RP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -185,11 +190,18 @@ __global__ __launch_bounds__(512, NJ == 8 ? 2 : 4) void ff_pair_kernel(const FFP
   int b, n0;
   bool live = true;
   if (a.skip_halo >= 0) {
+    // (one load of the lengths and one scan serve both questions -- how many live tiles are there, and which tile is mine: the dead tiles
+    // before row i are (i + 1) * tiles_n minus the live ones; a second pass over lens[] was a second dependent global round trip per workgroup)
     int nlive = 0;
+    int cnt0 = 0, inc0 = 0;                             // tile count of row `lane` and its inclusive scan (first 64 rows)
     for (int base = 0; base < a.B; base += 64) {
       const int i = base + lane;
       const int cnt = i < a.B ? min(tiles_n, max(0, (min(a.lens[i] + a.skip_halo, a.N) + FP_TOK - 1) / FP_TOK)) : 0;
-      nlive += fp_wave_sum_i(cnt);
+      int inc = cnt;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off, 64); if (lane >= off) inc += v; }
+      if (base == 0) { cnt0 = cnt; inc0 = inc; }
+      nlive += __shfl(inc, 63, 64);
     }
     int target = blockIdx.x;
     live = target < nlive;
@@ -198,11 +210,17 @@ __global__ __launch_bounds__(512, NJ == 8 ? 2 : 4) void ff_pair_kernel(const FFP
     b = 0; n0 = 0;
     for (int base = 0; base < a.B; base += 64) {
       const int i = base + lane;
-      const int cnt = i < a.B ? min(tiles_n, max(0, (min(a.lens[i] + a.skip_halo, a.N) + FP_TOK - 1) / FP_TOK)) : 0;
-      const int c = live ? cnt : (i < a.B ? tiles_n - cnt : 0);       // tiles of the wanted kind in this row
-      int inc = c;
+      int cnt, inc_live;
+      if (base == 0) { cnt = cnt0; inc_live = inc0; }
+      else {
+        cnt = i < a.B ? min(tiles_n, max(0, (min(a.lens[i] + a.skip_halo, a.N) + FP_TOK - 1) / FP_TOK)) : 0;
+        inc_live = cnt;
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off, 64); if (lane >= off) inc += v; }
+        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc_live, off, 64); if (lane >= off) inc_live += v; }
+      }
+      const int rows_here = min(64, a.B - base);
+      const int c = live ? cnt : (i < a.B ? tiles_n - cnt : 0);       // tiles of the wanted kind in this row
+      const int inc = live ? inc_live : min(lane + 1, rows_here) * tiles_n - inc_live;
       const unsigned long long hit = __ballot(target < run + inc);
       if (hit) {
         const int first = __builtin_ctzll(hit);
@@ -480,6 +498,7 @@ __global__ __launch_bounds__(512, NJ == 8 ? 2 : 4) void ff_pair_kernel(const FFP
     f32x4 acc[2][NJ];
     // hidden rows outside [0, N) are the second conv's zero padding: only the first / last tile of a batch row has any
     const bool edge = n0 == 0 || n0 + FP_TOK >= NL;
+    const int tile_lin = b * tiles_n + n0 / FP_TOK;    // position of the tile in the padded grid (the same in forward and backward)
     // bias + ReLU (forward) or the sign mask (backward), bf16, into slice image f & 1
 #define FP_PRODUCE(F_, COFLAG)                                                                                       \
     {                                                                                                                \
@@ -487,9 +506,14 @@ __global__ __launch_bounds__(512, NJ == 8 ? 2 : 4) void ff_pair_kernel(const FFP
       /* the bias is the C operand of the slice's first MFMAs: no add in the epilogue */                             \
       const f32x4 bv0 = a.bias_a ? *reinterpret_cast<const f32x4*>(a.bias_a + f0 + 32 * wq + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};      \
       const f32x4 bv1 = a.bias_a ? *reinterpret_cast<const f32x4*>(a.bias_a + f0 + 32 * wq + 16 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f}; \
-      bf16x4 av[2][NJ];                                                                                              \
+      bf16x4 av[2][MASK ? 1 : NJ];                                                                                   \
+      unsigned mw[2] = {0u, 0u};                                                                                     \
       FP_SLICE_STEPS(Xs, (F_) * 12,                                                                                  \
         if constexpr (AUX) {                                                                                         \
+          if constexpr (MASK) {                                                                                      \
+            const unsigned* mp_ = a.hmask + ((((size_t)tile_lin * nslices + (f0 >> 7)) * 4 + wq) * 2) * 64 + fp_opaque(lane); \
+            mw[0] = mp_[0]; mw[1] = mp_[64];                                                                         \
+          } else {                                                                                                   \
           const int r2_ = fp_opaque(r);                                                                              \
           const int g2_ = fp_opaque(g);                                                                              \
           _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                              \
@@ -497,6 +521,7 @@ __global__ __launch_bounds__(512, NJ == 8 ? 2 : 4) void ff_pair_kernel(const FFP
               const int n = min(max(n0 - 1 + 16 * j + r2_, 0), a.N - 1);                                             \
               av[i][j] = *reinterpret_cast<const bf16x4*>(a.aux + ((size_t)b * a.N + n) * a.ld_aux + f0 + 32 * wq + 16 * i + 4 * g2_); \
             }                                                                                                        \
+          }                                                                                                          \
         }, true, COFLAG, ((((F_) - 1) & 1) ? Hs1 : Hs0), slice_of((F_) - 1) << 7)                                    \
       unsigned char* const out = ((F_) & 1) ? Hs1 : Hs0;                                                             \
       const int r_ = fp_opaque(r);                                                                                   \
@@ -505,12 +530,32 @@ __global__ __launch_bounds__(512, NJ == 8 ? 2 : 4) void ff_pair_kernel(const FFP
       else _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                           \
         const int c = 32 * wq + 16 * i + 4 * g_;                                                                     \
         unsigned char* const orow = out + (c >> 6) * (FP_HR * 128) + fp_lds_off(r_, (c & 63) >> 3) + ((g_ & 1) << 3); \
+        unsigned sw_ = 0u;                                          /* forward: the sign word being built */        \
+        const unsigned mwi_ = mw[i];                                                                                 \
         _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                             \
           f32x4 v = acc[i][j];                                                                                       \
           if constexpr (AUX) {                                                                                       \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) if (!((float)av[i][j][e] > 0.f)) v[e] = 0.f;               \
+            if constexpr (MASK) {                                                                                    \
+              /* bit -> all-ones / zero (v_bfe_i32), AND with the value's bits: two instructions per element instead of load + convert + compare + select */ \
+              _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                        \
+                const float ve_ = v[e];                                                                              \
+                const unsigned ke_ = __float_as_uint(ve_) & (unsigned)__builtin_amdgcn_sbfe((int)mwi_, NJ * 4 - 1 - (j * 4 + e), 1); \
+                v[e] = __uint_as_float(ke_);                                                                         \
+              }                                                                                                      \
+            } else {                                                                                                 \
+              _Pragma("unroll") for (int e = 0; e < 4; ++e) if (!((float)av[i][j][e] > 0.f)) v[e] = 0.f;             \
+            }                                                                                                        \
           }                                                                                                          \
           if (edge) { const int n = n0 - 1 + 16 * j + r_; if (n < 0 || n >= NL) v = f32x4{0.f, 0.f, 0.f, 0.f}; }    \
+          if constexpr (RELU) {                                                                                      \
+            /* "> 0" of a float = its bits as a signed integer > 0: (bits - 1) has bit 31 clear; v_alignbit appends that bit to the word */ \
+            if (a.hmask) {                                                                                           \
+              _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                        \
+                const float ve_ = v[e];                                                                              \
+                sw_ = __builtin_amdgcn_alignbit(sw_, __float_as_uint(ve_) - 1u, 31);                                 \
+              }                                                                                                      \
+            }                                                                                                        \
+          }                                                                                                          \
           uint2 pk = fp_pack4(v[0], v[1], v[2], v[3]);                                                               \
           if constexpr (RELU) {                                                                                      \
             /* ReLU on the packed bf16 pairs: a negative float has its sign bit set, i.e. is a negative int16: max(., 0) zeroes it */ \
@@ -518,6 +563,9 @@ __global__ __launch_bounds__(512, NJ == 8 ? 2 : 4) void ff_pair_kernel(const FFP
             pk.y = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk.y), s16x2{0, 0})); \
           }                                                                                                          \
           *reinterpret_cast<uint2*>(orow + j * 2048) = pk;                                                           \
+        }                                                                                                            \
+        if constexpr (RELU) {                                       /* one coalesced dword per lane: bit = 1 where the value was > 0 */ \
+          if (a.hmask) a.hmask[((((size_t)tile_lin * nslices + (f0 >> 7)) * 4 + wq) * 2 + i) * 64 + fp_opaque(lane)] = ~sw_; \
         }                                                                                                            \
       }                                                                                                              \
     }
@@ -826,7 +874,7 @@ static int ff_pair_launch(const void* X, int ldx, const void* Wa, const void* Wb
                           const float* ln_res, const float* ln_w, const float* ln_b, const float* film, int ld_film,
                           float* ln_y, float* ln_mean, float* ln_rstd, unsigned long long seed_pre, float p_pre, const unsigned long long* seed_offset,
                           const float* lnb_z, const float* lnb_mean, const float* lnb_rstd, const float* lnb_w, const float* lnb_b,
-                          void* lnb_dg, float* lnb_dw, float* lnb_db, const FFPairArgs* prologue, void* stream) {
+                          void* lnb_dg, float* lnb_dw, float* lnb_db, const FFPairArgs* prologue, void* stream, unsigned* hmask = nullptr) {
   DX_REQUIRE((X || prologue) && Wa && Wb && Y, "dx_ff_pair: null pointer");
   DX_REQUIRE(H || (relu_mid && !lnb_w), "dx_ff_pair: only the forward pair may omit the mid-activation output H");
   if (ln_w) {
@@ -876,12 +924,15 @@ static int ff_pair_launch(const void* X, int ldx, const void* Wa, const void* Wb
   static bool configured = false;
   if (!configured) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_pair_kernel<true, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP<8>::IMG);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_pair_kernel<true, false, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP<8>::IMG);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_pair_kernel<true, false, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP<4>::IMG);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_pair_kernel<false, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP<8>::IMG);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_pair_kernel<true, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP<4>::IMG);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_pair_kernel<false, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP<4>::IMG);
     configured = true;
   }
   // tile width: 62-token tiles with two workgroups per CU (NJ = 4) or 126-token tiles with one (NJ = 8); DX_FF_NJ overrides (diagnostics)
+  a.hmask = hmask;
   static const int skew_env = getenv("DX_FF_SKEW") ? atoi(getenv("DX_FF_SKEW")) : 0;     // measured neutral (56.5 vs 56.6 us): off
   a.slice_skew = skew_env;
   static const int nj_env = getenv("DX_FF_NJ") ? atoi(getenv("DX_FF_NJ")) : 0;
@@ -889,10 +940,12 @@ static int ff_pair_launch(const void* X, int ldx, const void* Wa, const void* Wb
   hipStream_t s = (hipStream_t)stream;
   dx_prof_begin(DX_PROF_CONV_GEMM, s);
   if (nj == 8) {
-    if (aux) hipLaunchKernelGGL((ff_pair_kernel<true, false, 8>), dim3(B * dx_cdiv(N, FP<8>::TOK)), dim3(512), 3 * FP<8>::IMG, s, a);
+    if (aux && hmask) hipLaunchKernelGGL((ff_pair_kernel<true, false, 8, true>), dim3(B * dx_cdiv(N, FP<8>::TOK)), dim3(512), 3 * FP<8>::IMG, s, a);
+    else if (aux) hipLaunchKernelGGL((ff_pair_kernel<true, false, 8>), dim3(B * dx_cdiv(N, FP<8>::TOK)), dim3(512), 3 * FP<8>::IMG, s, a);
     else hipLaunchKernelGGL((ff_pair_kernel<false, true, 8>), dim3(B * dx_cdiv(N, FP<8>::TOK)), dim3(512), 3 * FP<8>::IMG, s, a);
   } else {
-    if (aux) hipLaunchKernelGGL((ff_pair_kernel<true, false, 4>), dim3(B * dx_cdiv(N, FP<4>::TOK)), dim3(512), 3 * FP<4>::IMG, s, a);
+    if (aux && hmask) hipLaunchKernelGGL((ff_pair_kernel<true, false, 4, true>), dim3(B * dx_cdiv(N, FP<4>::TOK)), dim3(512), 3 * FP<4>::IMG, s, a);
+    else if (aux) hipLaunchKernelGGL((ff_pair_kernel<true, false, 4>), dim3(B * dx_cdiv(N, FP<4>::TOK)), dim3(512), 3 * FP<4>::IMG, s, a);
     else hipLaunchKernelGGL((ff_pair_kernel<false, true, 4>), dim3(B * dx_cdiv(N, FP<4>::TOK)), dim3(512), 3 * FP<4>::IMG, s, a);
   }
   dx_prof_end(DX_PROF_CONV_GEMM, s);
@@ -914,11 +967,11 @@ int dx_ff_pair(const void* X, int ldx, const void* Wa, const void* Wb, const flo
 int dx_ff_pair_ln(const void* X, int ldx, const void* Wa, const void* Wb, const float* bias_a, const float* bias_b, void* H, int ldh, float* Z,
                   int B, int N, int F, const int* lens, int skip_halo, const int* rows_exist,
                   const float* res, const float* ln_w, const float* ln_b, const float* film, int ld_film, float* Yln, float* mean, float* rstd,
-                  uint64_t seed_pre, float p_pre, const uint64_t* seed_offset, void* stream) {
+                  uint64_t seed_pre, float p_pre, const uint64_t* seed_offset, void* hmask, void* stream) {
   DX_REQUIRE(ln_w != nullptr, "dx_ff_pair_ln: null pointer");
   return ff_pair_launch(X, ldx, Wa, Wb, bias_a, bias_b, nullptr, 0, H, ldh, Z, 128, B, N, F, 1, 0, lens, skip_halo, rows_exist,
                         res, ln_w, ln_b, film, ld_film, Yln, mean, rstd, (unsigned long long)seed_pre, p_pre, (const unsigned long long*)seed_offset,
-                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream, (unsigned*)hmask);
 }
 
 // dx_ff_pair_ln + the NEXT block's attention in-projection on the normalised tile: QKV = Yln x Wq^T + bias_q (16-bit [B][N][384]; Wq: the
@@ -926,13 +979,13 @@ int dx_ff_pair_ln(const void* X, int ldx, const void* Wa, const void* Wb, const 
 int dx_ff_pair_ln_qkv(const void* X, int ldx, const void* Wa, const void* Wb, const float* bias_a, const float* bias_b, void* H, int ldh, float* Z,
                       int B, int N, int F, const int* lens, int skip_halo, const int* rows_exist,
                       const float* res, const float* ln_w, const float* ln_b, const float* film, int ld_film, float* Yln, float* mean, float* rstd,
-                      uint64_t seed_pre, float p_pre, const uint64_t* seed_offset, const void* Wq, const float* bias_q, void* QKV, void* stream) {
+                      uint64_t seed_pre, float p_pre, const uint64_t* seed_offset, const void* Wq, const float* bias_q, void* QKV, void* hmask, void* stream) {
   DX_REQUIRE(ln_w != nullptr && Wq != nullptr, "dx_ff_pair_ln_qkv: null pointer");
   FFPairArgs ext{};
   ext.q_w = (const dx_h16*)Wq; ext.q_bias = bias_q; ext.q_out = (dx_h16*)QKV;
   return ff_pair_launch(X, ldx, Wa, Wb, bias_a, bias_b, nullptr, 0, H, ldh, Z, 128, B, N, F, 1, 0, lens, skip_halo, rows_exist,
                         res, ln_w, ln_b, film, ld_film, Yln, mean, rstd, (unsigned long long)seed_pre, p_pre, (const unsigned long long*)seed_offset,
-                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ext, stream);
+                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ext, stream, (unsigned*)hmask);
 }
 
 // The input-gradient pair with the backward of the block's FIRST LayerNorm folded into its epilogue:
@@ -960,7 +1013,7 @@ int dx_ff_block_bwd(const float* dY2, const float* z2, const float* mean2, const
                     const void* Wa, const void* Wb, const void* aux, int ld_aux, void* H, int ldh, float* Y,
                     int B, int N, int F, const int* lens, int skip_halo,
                     const float* z1, const float* mean1, const float* rstd1, const float* ln1_w, const float* ln1_b, void* DG1, float* dw1, float* db1,
-                    uint64_t seed1, float p1, const void* Wout_bwd, void* DATT, const uint64_t* seed_offset, void* stream) {
+                    uint64_t seed1, float p1, const void* Wout_bwd, void* DATT, const uint64_t* seed_offset, const void* hmask, void* stream) {
   DX_REQUIRE(ln1_w != nullptr && ln2_w != nullptr, "dx_ff_block_bwd: null pointer");
   DX_REQUIRE((Wout_bwd == nullptr) == (DATT == nullptr) && ((uintptr_t)Wout_bwd % 16) == 0 && ((uintptr_t)DATT % 16) == 0, "dx_ff_block_bwd: Wout_bwd and DATT come together, 16-byte aligned");
   DX_REQUIRE(p2 >= 0.f && p2 < 1.f, "dx_ff_block_bwd: dropout p out of range");
@@ -972,7 +1025,7 @@ int dx_ff_block_bwd(const float* dY2, const float* z2, const float* mean2, const
   pro.lnp_ld_dfilm = ld_dfilm; pro.lnp_seed = (unsigned long long)seed2; pro.lnp_thresh = (unsigned)lrintf(p2 * 65536.f); pro.lnp_inv_keep = 1.f / (1.f - p2);
   return ff_pair_launch(nullptr, 128, Wa, Wb, nullptr, nullptr, aux, ld_aux, H, ldh, Y, 128, B, N, F, 0, 1, lens, skip_halo, nullptr,
                         nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, (unsigned long long)seed1, p1, (const unsigned long long*)seed_offset,
-                        z1, mean1, rstd1, ln1_w, ln1_b, DG1, dw1, db1, &pro, stream);
+                        z1, mean1, rstd1, ln1_w, ln1_b, DG1, dw1, db1, &pro, stream, (unsigned*)hmask);
 }
 
 }  // extern "C"

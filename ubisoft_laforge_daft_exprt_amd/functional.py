@@ -187,13 +187,16 @@ class FFTBlockFn(torch.autograd.Function):
             y1, mean1, rstd1 = ln1[:3]
             y1g = ln1[3] if sh else y1             # the copy the GEMMs read
         fused = ops.ff_pair_applies(y1g, packs['c1'], packs['c2'], prec)
-        y2 = qkv_next = None
+        y2 = qkv_next = hmask = None
         if fused and ops._FF_LN:   # ... and the block's second LayerNorm on the output tile while it is still in LDS
             if next_in is not None and not ops.next_qkv_applies(next_in[0], prec):
                 next_in = None
+            need_bwd = any(ctx.needs_input_grad)
             z2, h, y2, mean2, rstd2, *rest = ops.ff_pair_ln(y1g, packs['c1'], packs['c2'], c1_b, c2_b, L, y1, ln2_w, ln2_b, film, seed_pre=s_ln2,
                                                             p_pre=p_conv, seed_offset=so, prec=prec, rows_exist=lens.exist, next_in=next_in,
-                                                            need_h=any(ctx.needs_input_grad))     # inference: the 2 KB/token hidden tensor is not written
+                                                            need_h=need_bwd,       # inference: the 2 KB/token hidden tensor is not written
+                                                            want_mask=need_bwd)    # training: + the ReLU sign words the backward reads instead of h
+            hmask = rest.pop() if need_bwd else None
             qkv_next = rest[0] if rest else None         # ... and the next block's in-projection on the normalised tile
         elif fused:    # conv1 + ReLU + conv2 in ONE launch, the 1024-wide hidden tile consumed from LDS (h is still written: weight gradients)
             z2, h = ops.ff_pair(y1g, packs['c1'], packs['c2'], c1_b, c2_b, L, prec=prec, rows_exist=lens.exist)
@@ -206,6 +209,7 @@ class FFTBlockFn(torch.autograd.Function):
         ctx.lens, ctx.packs, ctx.heads = lens, packs, heads
         ctx.drop = (p_attn, p_conv, s_attn, s_ln1, s_ln2)
         ctx.prec, ctx.sink, ctx.fused, ctx.seed_offset = prec, rt.sink, fused, so
+        ctx.hmask = hmask                          # (an int32 side tensor of the fused forward; None elsewhere)
         if qkv_next is not None:
             ctx.mark_non_differentiable(qkv_next)
         ctx.set_materialize_grads(False)           # else autograd hands backward a zero tensor the size of qkv_next (33 MB fill per block)
@@ -239,7 +243,7 @@ class FFTBlockFn(torch.autograd.Function):
                 dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, packs['c1'], packs['c2'], L, h, z1, mean1, rstd1, ln1_w, ln1_b,
                 seed2=s_ln2, p2=p_conv, seed1=s_ln1, p1=p_attn, seed_offset=so, prec=prec, arena=arena,
                 sinks={'ln2_w': g('ln2_w'), 'ln2_b': g('ln2_b'), 'ln1_w': g('ln1_w'), 'ln1_b': g('ln1_b')},
-                out_pack=packs['out'] if fuse_datt else None)
+                out_pack=packs['out'] if fuse_datt else None, hmask=ctx.hmask)
             dc2_w, dc2_b = ops.conv_wgrad(dff, h, packs['c2'], L, 0, arena=arena, w_sink=g('c2_w'), b_sink=g('c2_b'), prec=prec, defer=True)
         else:
             datt = None

@@ -318,13 +318,18 @@ def next_qkv_applies(pack_in: PackedWeight, prec) -> bool:
     return _FF_QKV and _half(prec) == 1 and pack_in.taps == 1 and pack_in.cin == 128 and pack_in.cout == 384
 
 
+_FF_MASK = os.environ.get('DX_FF_MASK', '1') != '0'
+
+
 def ff_pair_ln(x, pack1: PackedWeight, pack2: PackedWeight, bias1, bias2, lens, res, ln_w, ln_b, film, *, seed_pre=0, p_pre=0.0, seed_offset=None,
-               halo=1, prec=None, rows_exist=None, next_in=None, need_h=True):
+               halo=1, prec=None, rows_exist=None, next_in=None, need_h=True, want_mask=False):
     """The forward pair with the block's second LayerNorm folded into its epilogue (dx_ff_pair_ln).  Returns (z, h, y, mean, rstd):
     z = res + dropout(pair output) [fp32, what ln_fwd leaves in its input], y = mask(FiLM(LN(z))).
     ``next_in`` = (PackedWeight, bias) of the NEXT block's attention in-projection: the launch also produces that block's qkv
     (dx_ff_pair_ln_qkv) and a sixth value, the 16-bit (B, N, 384) tensor, is returned.
-    ``need_h=False`` (forward-only calls): the hidden tensor is not written and ``h`` is returned as None."""
+    ``need_h=False`` (forward-only calls): the hidden tensor is not written and ``h`` is returned as None.
+    ``want_mask``: one more value is appended to the result, the ReLU sign words of the hidden activation (int32 tensor, the C ABI's
+    ``hmask``) that ``ff_block_bwd`` takes instead of re-reading ``h``."""
     prec = pack1.rt.precision if prec is None else prec
     B, N, D = x.shape
     Fc = pack1.cout
@@ -334,6 +339,8 @@ def ff_pair_ln(x, pack1: PackedWeight, pack2: PackedWeight, bias1, bias2, lens, 
     y = torch.empty_like(z)
     mean = torch.empty(B, N, dtype=torch.float32, device=x.device)
     rstd = torch.empty(B, N, dtype=torch.float32, device=x.device)
+    mask = torch.empty(B * ((N + 125) // 126), Fc // 128, 4, 2, 64, dtype=torch.int32, device=x.device) if (want_mask and _FF_MASK) else None
+    tail = (mask,) if want_mask else ()
     _log(pack1, ('ffpair', B * N, N, 128, Fc, 3))
     if next_in is not None:
         pq, bq = next_in
@@ -341,12 +348,12 @@ def ff_pair_ln(x, pack1: PackedWeight, pack2: PackedWeight, bias1, bias2, lens, 
         _log(pq, ('conv', B * N, N, 128, 384, 1))
         _fn('dx_ff_pair_ln_qkv', prec)(_p(x), _rows(x), _p(i1.fwd), _p(i2.fwd), _p(bias1), _p(bias2), _p(h), Fc if h is None else _rows(h), _p(z), B, N, Fc, _p(lens), int(halo),
                                        _p(rows_exist), _p(res), _p(ln_w), _p(ln_b), _p(film), 0 if film is None else film.stride(0), _p(y), _p(mean),
-                                       _p(rstd), seed_pre, float(p_pre), _p(seed_offset), _p(pq.image(prec).fwd), _p(bq), _p(qkv), _stream())
-        return z, h, y, mean, rstd, qkv
+                                       _p(rstd), seed_pre, float(p_pre), _p(seed_offset), _p(pq.image(prec).fwd), _p(bq), _p(qkv), _p(mask), _stream())
+        return (z, h, y, mean, rstd, qkv) + tail
     _fn('dx_ff_pair_ln', prec)(_p(x), _rows(x), _p(i1.fwd), _p(i2.fwd), _p(bias1), _p(bias2), _p(h), Fc if h is None else _rows(h), _p(z), B, N, Fc, _p(lens), int(halo),
                                _p(rows_exist), _p(res), _p(ln_w), _p(ln_b), _p(film), 0 if film is None else film.stride(0), _p(y), _p(mean), _p(rstd),
-                               seed_pre, float(p_pre), _p(seed_offset), _stream())
-    return z, h, y, mean, rstd
+                               seed_pre, float(p_pre), _p(seed_offset), _p(mask), _stream())
+    return (z, h, y, mean, rstd) + tail
 
 
 
@@ -374,7 +381,7 @@ _FF_BLOCK_DATT = os.environ.get('DX_FF_BLOCK_DATT', '1') != '0'
 
 
 def ff_block_bwd(dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, pack1: PackedWeight, pack2: PackedWeight, lens, aux, z1, mean1, rstd1, ln1_w, ln1_b, *,
-                 seed2=0, p2=0.0, seed1=0, p1=0.0, seed_offset=None, halo=1, prec=None, arena=None, sinks=None, out_pack=None):
+                 seed2=0, p2=0.0, seed1=0, p1=0.0, seed_offset=None, halo=1, prec=None, arena=None, sinks=None, out_pack=None, hmask=None):
     """LayerNorm2-backward -> input-gradient pair -> LayerNorm1-backward in one launch (dx_ff_block_bwd).  ``sinks``: dict with optional
     pre-zeroed ``.grad`` tensors 'ln2_w', 'ln2_b', 'ln1_w', 'ln1_b'.  ``out_pack``: the attention out-projection's PackedWeight (128 x 128):
     the launch then also produces datt = dg1 x W_out.  Returns (dz1, dh, dg1_16bit, dg2_16bit, dfilm or None, dln2_w, dln2_b, dln1_w,
@@ -402,7 +409,7 @@ def ff_block_bwd(dy2, z2, mean2, rstd2, ln2_w, ln2_b, film, pack1: PackedWeight,
                                  _p(dg2), _p(acc['ln2_w']), _p(acc['ln2_b']), _p(dfilm), 256, seed2, float(p2),
                                  _p(i2.bwd), _p(i1.bwd), _p(aux), _rows(aux), _p(dh), _rows(dh), _p(dz1), B, N, Fc, _p(lens), int(halo),
                                  _p(z1), _p(mean1), _p(rstd1), _p(ln1_w), _p(ln1_b), _p(dg1), _p(acc['ln1_w']), _p(acc['ln1_b']),
-                                 seed1, float(p1), _p(wt), _p(datt), _p(seed_offset), _stream())
+                                 seed1, float(p1), _p(wt), _p(datt), _p(seed_offset), _p(hmask), _stream())
     ret = lambda k: None if sinks.get(k) is not None else acc[k]
     return dz1, dh, dg1, dg2, dfilm, ret('ln2_w'), ret('ln2_b'), ret('ln1_w'), ret('ln1_b'), datt
 
