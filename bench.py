@@ -102,6 +102,11 @@ def main():
         raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # ONE JSON line on stdout, nothing else: librccl prints a version banner to stdout when the process group comes up (seen in the one-rank
+    # rehearsal), so from here on file descriptor 1 is stderr for every library in this process and the result goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
     # Rehearsal of the multi-rank path on a ONE-GPU box (DX_BENCH_REHEARSAL=1): every rank uses cuda:0 and the gradients travel over gloo.
@@ -111,6 +116,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    if world == 1 and os.environ.get('DX_FORCE_COLLECTIVES', '0') == '1':
+        # one-rank RCCL group on the one GPU: the N > 1 code path (four phases, four graphs, an RCCL all-reduce launched between the replays)
+        # end to end with the real backend; there is nobody to exchange with, so the collectives move no data between GPUs
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if rehearsal:
@@ -340,8 +351,8 @@ def main():
             avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
             cores = min(avail, 16)                                       # a 1-GPU box is given a 16-CPU share
             result['cpu_baseline'] = cpu_baseline(hp, cores, args.config, n_speakers)
-        print(json.dumps(result), flush=True)
-    if world > 1:
+        os.write(json_fd, (json.dumps(result) + '\n').encode())
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

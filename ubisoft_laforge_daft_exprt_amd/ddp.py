@@ -39,6 +39,9 @@ class GradientReducer:
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # DX_FORCE_COLLECTIVES=1 (rehearsal on one GPU with a one-rank RCCL group): issue the all-reduces although there is nobody to exchange with
+        import os
+        self.collective = self.world > 1 or (dist.is_initialized() and os.environ.get('DX_FORCE_COLLECTIVES', '0') == '1')
         if self.world > 1 and broadcast_parameters:
             src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
             with torch.no_grad():
@@ -108,7 +111,7 @@ class GradientReducer:
             self.seen[bi] += 1
             return
         self.pending[bi] -= 1
-        if self.pending[bi] == 0 and self.world > 1 and self.sync:
+        if self.pending[bi] == 0 and self.collective and self.sync:
             op = self._reduce_op()
             work = dist.all_reduce(self.flat[bi], op=op, group=self.group, async_op=True)
             self.works.append((work, bi, op))
@@ -169,7 +172,7 @@ class GradientReducer:
             if gid is None or self.bucket_group[bi] == gid:
                 self.pending[bi] = 0
                 self.launched.add(bi)
-                if self.world > 1:
+                if self.collective:
                     op = self._reduce_op()
                     self.works.append((dist.all_reduce(flat, op=op, group=self.group, async_op=True), bi, op))
 

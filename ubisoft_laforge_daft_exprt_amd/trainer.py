@@ -78,7 +78,7 @@ class Trainer:
         self.device = next(model.parameters()).device
         import torch.distributed as dist
         world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.cut_levels = (3 if world > 1 else 0) if cuts == 'auto' else int(cuts)
+        self.cut_levels = (3 if (world > 1 or os.environ.get('DX_FORCE_COLLECTIVES', '0') == '1') else 0) if cuts == 'auto' else int(cuts)
         if not 0 <= self.cut_levels <= 3:
             raise ValueError(f'cuts must be 0..3 or "auto", got {cuts!r}')
         self.reducer = GradientReducer(model, bucket_mb=bucket_mb, process_group=process_group, grad_sink=grad_sink,
