@@ -411,14 +411,15 @@ def _attention_dropout_mask_consistency(ops, tol_f, tol_b):
 
 @pytest.mark.parametrize('precision', ['bf16', 'fp16'])
 @pytest.mark.parametrize('p_drop', [0.0, 0.2])
-def test_ff_pair_backward_layernorm_epilogue_equals_two_launches(ops, precision, p_drop):
+@pytest.mark.parametrize('rep', [1, 7])      # 5 / 35 utterances: 62-token tiles (short batches) / 126-token tiles (>= 96 of them)
+def test_ff_pair_backward_layernorm_epilogue_equals_two_launches(ops, precision, p_drop, rep):
     """dx_ff_pair_lnbwd == dx_ff_pair(backward, accumulate) followed by dx_ln_bwd (same seeds): dz1, its dropped-out 16-bit copy, dh and the
     affine gradients; lengths on a tile edge, on the halo row and inside a tile."""
     ops.set_precision(precision)
     try:
         h16 = ops.hidden_dtype()
-        B, N, Fc = 5, 300, 1024
-        lens = lens_tensor([300, 252, 126, 127, 40])
+        B, N, Fc = 5 * rep, 300, 1024
+        lens = lens_tensor([300, 252, 126, 127, 40] * rep)
         valid = (torch.arange(N, device=DEV)[None, :] < lens[:, None])
         vf = valid[:, :, None].float()
         w1 = randn(Fc, 128, 3, seed=2, scale=1 / math.sqrt(384))
@@ -447,14 +448,15 @@ def test_ff_pair_backward_layernorm_epilogue_equals_two_launches(ops, precision,
 
 @pytest.mark.parametrize('precision', ['bf16', 'fp16'])
 @pytest.mark.parametrize('p_drop,use_film', [(0.0, True), (0.2, True), (0.2, False)])
-def test_ff_block_backward_equals_three_launches(ops, precision, p_drop, use_film):
+@pytest.mark.parametrize('rep', [1, 7])      # 5 / 35 utterances: 62-token tiles (short batches) / 126-token tiles (>= 96 of them)
+def test_ff_block_backward_equals_three_launches(ops, precision, p_drop, use_film, rep):
     """dx_ff_block_bwd == dx_ln_bwd (second LayerNorm) + dx_ff_pair (input-gradient pair, accumulate) + dx_ln_bwd (first LayerNorm), same
     seeds: dz1, both 16-bit gradient copies, the hidden gradient, the affine and FiLM gradients; lengths on tile edges and halo rows."""
     ops.set_precision(precision)
     try:
         h16 = ops.hidden_dtype()
-        B, N, Fc = 5, 300, 1024
-        lens = lens_tensor([300, 252, 126, 127, 40])
+        B, N, Fc = 5 * rep, 300, 1024
+        lens = lens_tensor([300, 252, 126, 127, 40] * rep)
         valid = (torch.arange(N, device=DEV)[None, :] < lens[:, None])
         vf = valid[:, :, None].float()
         w1 = randn(Fc, 128, 3, seed=2, scale=1 / math.sqrt(384))
@@ -495,15 +497,16 @@ def test_ff_block_backward_equals_three_launches(ops, precision, p_drop, use_fil
 
 
 @pytest.mark.parametrize('precision', ['bf16', 'fp16'])
-def test_ff_block_backward_with_sign_words_equals_the_stored_activation(ops, precision):
+@pytest.mark.parametrize('rep', [1, 7])      # 5 / 35 utterances: 62-token tiles (short batches) / 126-token tiles (>= 96 of them)
+def test_ff_block_backward_with_sign_words_equals_the_stored_activation(ops, precision, rep):
     """The backward's ReLU mask from the forward's sign words (``hmask``: one bit per hidden element in the kernel's register layout) is the
     mask ``h > 0`` it replaces: same hidden gradient, same dz1, bit for bit; utterances on tile edges, on the halo row, inside a tile and
     longer than one tile."""
     ops.set_precision(precision)
     try:
         h16 = ops.hidden_dtype()
-        B, N, Fc = 6, 300, 1024
-        lens = lens_tensor([300, 252, 126, 127, 40, 1])
+        B, N, Fc = 6 * rep, 300, 1024
+        lens = lens_tensor([300, 252, 126, 127, 40, 1] * rep)
         valid = (torch.arange(N, device=DEV)[None, :] < lens[:, None])
         vf = valid[:, :, None].float()
         w1 = randn(Fc, 128, 3, seed=2, scale=1 / math.sqrt(384))
@@ -577,14 +580,15 @@ def test_film_affine_forward_backward_vs_torch(ops, with_pm):
 
 @pytest.mark.parametrize('precision', ['bf16', 'fp16'])
 @pytest.mark.parametrize('p_drop', [0.0, 0.2])
-def test_ff_pair_layernorm_epilogue_equals_two_launches(ops, precision, p_drop):
+@pytest.mark.parametrize('rep', [1, 7])      # 5 / 35 utterances: 62-token tiles (short batches) / 126-token tiles (>= 96 of them)
+def test_ff_pair_layernorm_epilogue_equals_two_launches(ops, precision, p_drop, rep):
     """dx_ff_pair_ln == dx_ff_pair followed by dx_ln_fwd (same seeds): z, statistics, y, the hidden tensor; lengths that put the last tile on
     the halo row, on a tile edge and inside a tile; FiLM on and off."""
     ops.set_precision(precision)
     try:
         h16 = ops.hidden_dtype()
-        B, N, Fc = 5, 300, 1024
-        lens = lens_tensor([300, 252, 126, 127, 40])
+        B, N, Fc = 5 * rep, 300, 1024
+        lens = lens_tensor([300, 252, 126, 127, 40] * rep)
         valid = (torch.arange(N, device=DEV)[None, :] < lens[:, None])
         x = (randn(B, N, 128, seed=1) * valid[:, :, None]).to(h16)
         w1, b1 = randn(Fc, 128, 3, seed=2, scale=1 / math.sqrt(384)), randn(Fc, seed=3, scale=0.1)
@@ -605,15 +609,16 @@ def test_ff_pair_layernorm_epilogue_equals_two_launches(ops, precision, p_drop):
 
 
 @pytest.mark.parametrize('precision', ['bf16', 'fp16'])
-def test_ff_pair_epilogue_produces_next_blocks_qkv(ops, precision):
+@pytest.mark.parametrize('rep', [1, 7])      # 5 / 35 utterances: 62-token tiles (short batches) / 126-token tiles (>= 96 of them)
+def test_ff_pair_epilogue_produces_next_blocks_qkv(ops, precision, rep):
     """dx_ff_pair_ln_qkv == dx_ff_pair_ln followed by the next block's in-projection launch (dx_conv_gemm 128 -> 384, halo 0) on its y:
     everything dx_ff_pair_ln returns is unchanged bit for bit; qkv agrees to the rounding of its 16-bit storage (other fp32 summation
     order), equals the bias on padded rows of live tiles and zero in tiles beyond the halo."""
     ops.set_precision(precision)
     try:
         h16 = ops.hidden_dtype()
-        B, N, Fc = 5, 300, 1024
-        lens_l = [300, 252, 126, 127, 40]
+        B, N, Fc = 5 * rep, 300, 1024
+        lens_l = [300, 252, 126, 127, 40] * rep
         lens = lens_tensor(lens_l)
         valid = (torch.arange(N, device=DEV)[None, :] < lens[:, None])
         x = (randn(B, N, 128, seed=1) * valid[:, :, None]).to(h16)
@@ -639,8 +644,9 @@ def test_ff_pair_epilogue_produces_next_blocks_qkv(ops, precision):
             diff = (q1.float() - q0.float()).abs()[valid]              # (padded rows: the two launches tile the axis differently, see below)
             assert float((diff / q0.float()[valid].abs().clamp_min(0.25)).max()) <= 2 * ulp   # at most a rounding step of the 16-bit result
             assert float((diff > 0).float().mean()) < 0.02                                        # and only where the fp32 sums straddle one
+            tok = 126 if B * -(-N // 126) >= 96 else 62                                           # the tile width the launch chose for this shape
             for b, n in enumerate(lens_l):
-                live_end = min(N, -(-(n + 1) // 126) * 126)                                      # the 126-token tiles that start before len + halo (1)
+                live_end = min(N, -(-(n + 1) // tok) * tok)                                      # the tiles that start before len + halo (1)
                 if n < live_end:
                     assert torch.equal(q1[b, n:live_end].float(), bq.to(h16).float().expand(live_end - n, 384))
                 assert float(q1[b, live_end:].float().abs().max() if live_end < N else 0.0) == 0.0

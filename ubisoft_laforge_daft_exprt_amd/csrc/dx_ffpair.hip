@@ -43,8 +43,10 @@ namespace {
 // row-pass epilogues, during which the CU's matrix pipes idle.  NJ = 4 (62 output tokens, 51 KB, <= 128 registers) lets TWO workgroups share
 // a CU: four waves per SIMD, and one workgroup's fill / drain / epilogue runs beside the other's slice loop.  The price: every weight
 // fragment is reused by 4 instead of 8 MFMAs, i.e. twice the L2 -> register weight traffic per FLOP (768 MB per launch), and at the
-// 128-register cap the kernel spills 41-45 registers.  MEASURED (round 3, C2 frame axis, same box): NJ = 4 is slower -- forward 80-93 us
-// against 56, backward 96-101 against 68 -- so NJ = 8 stays the default and NJ = 4 is kept only as the recorded experiment (DX_FF_NJ=4).
+// 128-register cap the kernel spills 41-45 registers.  MEASURED (round 3, C2 frame axis, same box): NJ = 4 with two workgroups per CU is
+// slower -- forward 80-93 us against 56, backward 96-101 against 68 -- so the frame axis stays on NJ = 8.  NJ = 4 (built at 256 registers,
+// no spills, one workgroup per CU) serves the SHORT batches instead: the symbol axis (48 x <= 120 symbols) is 48 tiles of 126 tokens but
+// 96 of 62, and the fused forms then replace four (forward) and five (backward) latency-bound launches per symbol-level block.
 template <int NJ> struct FP {
   static constexpr int NROW = NJ * 16;       // hidden rows of a tile = MFMA columns of the first conv
   static constexpr int TOK = NROW - 2;       // output tokens per workgroup
@@ -137,7 +139,7 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 // MASK (backward only): the ReLU gradient mask comes from the forward's sign words (a.hmask) instead of the stored activation (a.aux) --
 // a compile-time choice: with both paths in one kernel the aux prefetch registers stay allocated and the kernel spills
 template <bool AUX, bool RELU, int NJ, bool MASK = false>
-__global__ __launch_bounds__(512, NJ == 8 ? 2 : 4) void ff_pair_kernel(const FFPairArgs a) {
+__global__ __launch_bounds__(512, 2) void ff_pair_kernel(const FFPairArgs a) {
   constexpr int FP_TOK = FP<NJ>::TOK, FP_HR = FP<NJ>::HR, FP_IMG = FP<NJ>::IMG, NROW = FP<NJ>::NROW, XP = FP<NJ>::XP, RP = FP<NJ>::RP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const Xs = smem;
@@ -936,7 +938,10 @@ static int ff_pair_launch(const void* X, int ldx, const void* Wa, const void* Wb
   static const int skew_env = getenv("DX_FF_SKEW") ? atoi(getenv("DX_FF_SKEW")) : 0;     // measured neutral (56.5 vs 56.6 us): off
   a.slice_skew = skew_env;
   static const int nj_env = getenv("DX_FF_NJ") ? atoi(getenv("DX_FF_NJ")) : 0;
-  const int nj = nj_env == 8 || nj_env == 4 ? nj_env : 8;     // NJ = 4 measured SLOWER (fwd 80-93 vs 56 us, bwd 96-101 vs 68): see FP<NJ>
+  // Tile width by shape: 126-token tiles where they fill the chip (frame axis: ~250 live tiles at C2); 62-token tiles for short batches
+  // (symbol axis: 48 utterances of <= 120 symbols are 48 tiles of 126 but 96 of 62: twice the CUs, half the serial slice loop per workgroup).
+  // Forward and backward see the same (B, N) and therefore make the same choice (the sign words are laid out per tile).
+  const int nj = nj_env == 8 || nj_env == 4 ? nj_env : (B * dx_cdiv(N, FP<8>::TOK) >= 96 ? 8 : 4);
   hipStream_t s = (hipStream_t)stream;
   dx_prof_begin(DX_PROF_CONV_GEMM, s);
   if (nj == 8) {

@@ -271,7 +271,8 @@ def conv_gemm(x, pack: PackedWeight, bias=None, *, transpose=False, relu=False, 
     return out
 
 
-_FF_FUSED_MIN_TILES = int(os.environ.get('DX_FF_FUSED_MIN_TILES', '96'))
+_FF_FUSED_MIN_TILES = int(os.environ.get('DX_FF_FUSED_MIN_TILES', '96'))       # 126-token tiles (the frame axis)
+_FF_FUSED_MIN_TILES62 = int(os.environ.get('DX_FF_FUSED_MIN_TILES62', '64'))   # 62-token tiles (short batches: the symbol axis)
 
 
 def ff_pair_applies(x, pack1: PackedWeight, pack2: PackedWeight, prec) -> bool:
@@ -280,7 +281,7 @@ def ff_pair_applies(x, pack1: PackedWeight, pack2: PackedWeight, prec) -> bool:
     batches (48 tiles at C2: measured 40 vs 37 us forward, 55 vs 42 us backward) stay on the two-launch path."""
     return (prec in _H16 and x.dtype == _H16[prec] and x.dim() == 3 and x.shape[2] == 128 and pack1.taps == 3 and pack2.taps == 3
             and pack1.cin == 128 and pack2.cout == 128 and pack2.cin == pack1.cout and pack1.cout % 128 == 0
-            and x.shape[0] * ((x.shape[1] + 125) // 126) >= _FF_FUSED_MIN_TILES)
+            and (x.shape[0] * ((x.shape[1] + 125) // 126) >= _FF_FUSED_MIN_TILES or x.shape[0] * ((x.shape[1] + 61) // 62) >= _FF_FUSED_MIN_TILES62))
 
 
 def ff_pair(x, pack1: PackedWeight, pack2: PackedWeight, bias1, bias2, lens, *, backward=False, aux=None, out=None, accumulate=False,
@@ -339,7 +340,7 @@ def ff_pair_ln(x, pack1: PackedWeight, pack2: PackedWeight, bias1, bias2, lens, 
     y = torch.empty_like(z)
     mean = torch.empty(B, N, dtype=torch.float32, device=x.device)
     rstd = torch.empty(B, N, dtype=torch.float32, device=x.device)
-    mask = torch.empty(B * ((N + 125) // 126), Fc // 128, 4, 2, 64, dtype=torch.int32, device=x.device) if (want_mask and _FF_MASK) else None
+    mask = torch.empty(B * ((N + 61) // 62), Fc // 128, 4, 2, 64, dtype=torch.int32, device=x.device) if (want_mask and _FF_MASK) else None     # (room for either tile width)
     tail = (mask,) if want_mask else ()
     _log(pack1, ('ffpair', B * N, N, 128, Fc, 3))
     if next_in is not None:
