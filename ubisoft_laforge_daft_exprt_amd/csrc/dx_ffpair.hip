@@ -178,7 +178,10 @@ __global__ __launch_bounds__(512, 2) void ff_pair_kernel(const FFPairArgs a) {
     const int f = slice_of(it_);
     return wbase + (size_t)f * w_slice + (s >> 2) * w_tap + (s & 3) * 512;
   };
-  f32x4 wr[4][2];                                     // ring of 4 steps
+  // ring of RING steps: a step is 2 * NJ MFMAs per wave (NJ = 8: 256 cycles, four steps ahead = ~1 k cycles of cover for an L2 round trip; NJ = 4:
+  // 128 cycles per step, so six steps ahead -- 12 steps per slice keep the slot of a step a compile-time constant for 4 and 6)
+  constexpr int RING = NJ == 8 ? 4 : 6;
+  f32x4 wr[RING][2];
 #define FP_WLOAD(SLOT, GS)                                                                                           \
   {                                                                                                                  \
     const char* p_ = reinterpret_cast<const char*>(w_ptr(GS));                                                       \
@@ -305,6 +308,7 @@ __global__ __launch_bounds__(512, 2) void ff_pair_kernel(const FFPairArgs a) {
       rsv[it] = valid ? a.lnp_rstd[grow] : 0.f;
     }
     FP_WLOAD(0, 0) FP_WLOAD(1, 1) FP_WLOAD(2, 2) FP_WLOAD(3, 3)      // first weight fragments: in flight beside the row arithmetic
+    if constexpr (RING == 6) { FP_WLOAD(4, 4) FP_WLOAD(5, 5) }
 #pragma unroll
     for (int it = 0; it < RP; ++it) {
       const int row = (tid >> 4) + it * 32, n = n0 - 2 + row;
@@ -398,6 +402,7 @@ __global__ __launch_bounds__(512, 2) void ff_pair_kernel(const FFPairArgs a) {
       xr[it] = v;
     }
     FP_WLOAD(0, 0) FP_WLOAD(1, 1) FP_WLOAD(2, 2) FP_WLOAD(3, 3)      // first weight fragments: in flight beside the tile loads
+    if constexpr (RING == 6) { FP_WLOAD(4, 4) FP_WLOAD(5, 5) }
     // rows 128, 129 of both hidden images stay zero for the whole kernel (the last two MFMA columns of the second conv read them)
     if (tid < 64) {
       const int img = tid >> 5, rr = NROW + ((tid >> 4) & 1), q = tid & 15;
@@ -467,7 +472,7 @@ __global__ __launch_bounds__(512, 2) void ff_pair_kernel(const FFPairArgs a) {
     else { _Pragma("unroll") for (int j = 0; j < NJ; ++j) NXT[j] = CUR[j]; }                                         \
     if ((CO) && DX_FP_ABL != 4 && (S) < NJ && ((S) & 1) == 0) FP_CO_RD((S) >> 1, IMGC)                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
-    const f32x4 w0 = wr[(S) & 3][0], w1 = wr[(S) & 3][1];                                                            \
+    const f32x4 w0 = wr[(S) % RING][0], w1 = wr[(S) % RING][1];                                                      \
     if ((FRESH) && (S) == 0) {                                  /* a producer slice starts from the bias as the C operand */ \
       _Pragma("unroll") for (int j = 0; j < NJ; ++j) { acc[0][j] = bv0; FP_MMA(w0, CUR[j], acc[0][j]) }              \
       _Pragma("unroll") for (int j = 0; j < NJ; ++j) { acc[1][j] = bv1; FP_MMA(w1, CUR[j], acc[1][j]) }              \
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(512, 2) void ff_pair_kernel(const FFPairArgs a) {
       _Pragma("unroll") for (int j = 0; j < NJ; ++j) { FP_MMA(w0, CUR[j], acc[0][j]) }                               \
       _Pragma("unroll") for (int j = 0; j < NJ; ++j) { FP_MMA(w1, CUR[j], acc[1][j]) }                               \
     }                                                                                                                \
-    if (DX_FP_ABL != 1 && DX_FP_ABL != 4) FP_WLOAD((S) & 3, (GS0) + (S) + 4)                                                           \
+    if (DX_FP_ABL != 1 && DX_FP_ABL != 4) FP_WLOAD((S) % RING, (GS0) + (S) + RING)                                                     \
     if ((CO) && DX_FP_ABL != 4 && (S) < NJ && ((S) & 1) == 1) FP_CO_ST((S) >> 1, F0C)                                                  \
     if ((S) == 8) { AUXPF }                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                               \

@@ -67,6 +67,8 @@ class Lengths:
     def order(self):
         """device int32 [B]: utterance indices, longest first (ops.length_order) -- computed by one tiny launch on first use (under graph
         capture: recorded, so every replay re-derives it from the static length buffer).  Attention workgroups are handed out in this order."""
+        if not ops._ATTN_ORDER:
+            return None
         if self._order is None:
             self._order = ops.length_order(self.i32)
         return self._order
