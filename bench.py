@@ -319,6 +319,16 @@ def main():
                   'worst_grad_rel': pr.get('worst_grad_rel'), 'worst_grad_cos': pr.get('worst_grad_cos'),
                   'source': 'profiles/' + os.path.basename(recs[-1]) + ' (tests/test_configs_gpu.py on MI355X)'}
 
+    # whole-step algorithmic MFMA rate, SURVEY.md section 8(d): F_fwd(L, T) per utterance on VALID tokens, forward + backward = 3 x forward
+    def f_fwd(L, T):
+        fft = lambda n: n * 1703936 + 512 * n * n
+        return T * 7569408 + T * 1536 + 8 * fft(T) + 4 * fft(L) + L * (3 * 768 + 256) + L * T * (8 + 2 * 128) + T * 20480 + 600000
+    step_flop = 3.0 * sum(f_fwd(int(l), int(t)) for l, t in zip(batch[5].tolist(), batch[9].tolist())) * world
+    whole_step = {'algorithmic_tflop_per_step': round(step_flop / 1e12, 4), 'achieved_tflops': round(step_flop / 1e12 / (elapsed / args.steps), 1),
+                  'peak_tflops': 2500.0 if args.precision != 'f32' else 157.3 * 1.0,
+                  'formula': 'SURVEY.md section 8(d): 3 x sum_b F_fwd(L_b, T_b), valid tokens only (the frozen pitch predictor of the loss is extra work that is not credited)'}
+    whole_step['frac'] = round(whole_step['achieved_tflops'] / (whole_step['peak_tflops'] * world), 4)
+
     if rank == 0:
         result = {
             'metric': 'mel frames/sec (fwd+bwd)', 'value': round(total_frames * args.steps / elapsed, 1), 'unit': 'valid mel frames/s',
@@ -339,6 +349,7 @@ def main():
         result['rccl_ranks'] = dist.get_world_size() if world > 1 else 1
         result['exposed_allreduce_ms_per_step'] = round(exposed_ms, 4)
         result['host_enqueue_ms_per_step'] = round(1e3 * host_s / args.steps, 3)
+        result['whole_step'] = whole_step
         result['exchange'] = trainer.exchange_plan()     # per group: bytes, launch point; exposed_bytes = the group launched after the last backward kernel
         result.update(extras)
         if parity is not None:

@@ -561,7 +561,7 @@ def attention_fwd(qkv, lens, heads, seed, p_drop, prec=None, seed_offset=None, c
     prec = prec or DEFAULT.precision
     _check_h16(prec, qkv, ctx)
     _fn('dx_attention_fwd', prec)(_p(qkv), _rows(qkv), _p(lens), _p(ctx), D, _p(lse), B, N, heads, D, seed, _p(seed_offset), float(p_drop),
-                           _half(prec), _is_bf16(qkv), _is_bf16(ctx), _p(order if _ATTN_ORDER else None), _stream())
+                           _half(prec), _is_bf16(qkv), _is_bf16(ctx), _p(order), _stream())
     return ctx, lse
 
 
@@ -575,7 +575,7 @@ def attention_bwd(qkv, ctx, dctx, lse, lens, heads, seed, p_drop, out_dtype=torc
     prec = prec or DEFAULT.precision
     _fn('dx_attention_bwd', prec)(_p(qkv), _rows(qkv), _p(ctx), _p(dctx), _rows(dctx), _p(lse), _p(delta), _p(lens), _p(dqkv), _rows(dqkv),
                            B, N, heads, D, seed, _p(seed_offset), float(p_drop), _half(prec), _is_bf16(qkv), _is_bf16(dqkv), _is_bf16(ctx),
-                           _p(order if _ATTN_ORDER else None), _stream())
+                           _p(order), _stream())
     return dqkv
 
 
