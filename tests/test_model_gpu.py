@@ -141,6 +141,46 @@ def test_forward_backward_vs_oracle_c1(dx):
     print('worst gradient relative error vs oracle', worst)
 
 
+def test_forward_backward_vs_oracle_c3_speakers(dx):
+    """BASELINE.json configs[2] (C3: LJ + ESD, 11 speakers -> ``n_speakers`` = 12, ``hparams.py:199-200``) on ONE GPU: what a rank of the
+    8-GPU job computes.  The speaker classifier's last layer is then (12, 128) (a multiple of 4: no zero padding), speaker ids span 0..10 and
+    the adversarial cross-entropy is a 12-way softmax.  Forward, the 7 loss terms and every gradient against the CPU oracle, f32 mode."""
+    from oracle import daft_exprt_oracle as oracle
+    from ubisoft_laforge_daft_exprt_amd.synth import synthetic_batch, synthetic_state_dict
+    hp = helpers.golden_hparams().clone(n_speakers=12)
+    batch = synthetic_batch(6, (20, 48), seed=1303, n_speakers=12, zero_dur_frac=0.1)
+    assert 1 <= int(batch[10].max()) <= 10
+    model = dx.DaftExprt(hp).to(DEV)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert shapes['speaker_classifier.classifier.5.linear_layer.weight'] == (12, 128)
+    sd = synthetic_state_dict(shapes, 4321)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    inputs, targets = model.parse_batch(DEV, batch)
+    targets = targets + (inputs[6], inputs[7])
+    outputs = model(inputs)
+    crit = build_loss(dx, hp)
+    total, terms = crit(outputs, targets, 4000)
+    total.backward()
+    for v in sd.values():
+        v.requires_grad_(True)
+    cpu_inputs = tuple(batch[i] for i in range(11)) + (batch[13],)
+    cpu_targets = (batch[1], batch[3], batch[4], batch[8], batch[9], batch[10], batch[6], batch[7])
+    ref_out = oracle.forward(sd, cpu_inputs, hp, training=True)
+    ref_total, ref_terms = oracle.loss(ref_out, cpu_targets, 4000, hp, helpers.golden_pitch_predictor_state_dict())
+    ref_total.backward()
+    assert outputs[0].shape == (6, 12) and float((outputs[0].detach().cpu() - ref_out[0].detach()).abs().max()) < 1e-4
+    l1 = valid_mel_l1(outputs[3][0].detach().cpu().numpy(), ref_out[3][0].detach().numpy(), batch[9])
+    assert l1 < 2e-5, l1
+    assert abs(total.item() - ref_total.item()) <= 2e-5 * abs(ref_total.item())
+    for k, v in terms.items():
+        assert abs(v - float(ref_terms[k])) <= 5e-5 * max(1.0, abs(float(ref_terms[k]))), k
+    for k, p in model.named_parameters():
+        g, r = p.grad.detach().cpu(), sd[k].grad
+        assert ((g - r).abs().max() / r.abs().max().clamp_min(1e-10)).item() < 3e-3, k
+    print(f'C3 (12 speakers): valid mel L1 vs oracle {l1:.2e}, speaker_ce_raw {terms["speaker_ce_raw"]:.4f}')
+
+
 @pytest.mark.parametrize('name,transform', [('inference_add', 'add'), ('inference_multiply', 'multiply')])
 def test_inference_vs_golden(dx, name, transform):
     case = helpers.load_case(name)
