@@ -15,7 +15,7 @@ from collections import defaultdict
 # bench.py / profiling.py kernel label -> regex on the (demangled) rocprof kernel name.  A label may cover several device kernels
 # (the attention backward is a dQ and a dK/dV launch per call): their per-call figures add up.
 LABELS = [
-    ('ff_pair_kernel<fwd>', r'ff_pair_kernel<false, true>'), ('ff_pair_kernel<bwd>', r'ff_pair_kernel<true, false>'),
+    ('ff_pair_kernel<fwd>', r'ff_pair_kernel<false, true'), ('ff_pair_kernel<bwd>', r'ff_pair_kernel<true, false'),
     ('conv_dk_kernel<3>', r'conv_dk_kernel<3,'), ('conv_dk_kernel<1>', r'conv_dk_kernel<1,'),
     ('conv_ws_kernel<3>', r'conv_ws_kernel<3,'), ('conv_ws_kernel<1>', r'conv_ws_kernel<1,'),
     ('conv_gemm_kernel<bf16>', r'conv_gemm_kernel<(__bf16|__hip_bfloat16|DF16b)|conv_gemm_kernelIDF16|conv_gemm_kernel<bool'), ('conv_gemm_kernel<f32>', r'conv_gemm_kernel<float'),

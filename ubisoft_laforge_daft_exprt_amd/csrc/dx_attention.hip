@@ -34,6 +34,7 @@ struct AttnArgs {
   uint64_t seed; uint32_t thresh; float inv_keep;
   const uint64_t* seed_offset;     // optional device scalar added to `seed` (captured HIP graphs: a new dropout stream per replay)
   const int* order;                // optional [B]: utterance indices, longest first (dx_length_order): blockIdx.z -> utterance
+  int xcd_map;                     // 1: workgroups renumbered so that the tiles of an (utterance, head) pair share an XCD (attn_block)
 };
 
 __device__ __forceinline__ f32x4 mma4(const float4& a, const float4& b, f32x4 c) {
@@ -54,6 +55,25 @@ __device__ __forceinline__ void stage_tile(float* dst, const float* base, int ld
   }
 }
 
+// Workgroup -> (tile, head, utterance).  The tiles of one (utterance, head) pair all stream the same K / V (Q / dO) rows; dispatched in grid
+// order (x fastest) consecutive tiles go to 8 DIFFERENT XCDs, so every XCD's L2 fetches the pair's operands for itself (PMC: 3.2-3.6x the
+// algorithmic bytes, 3.7 GB of the step's ~16 GB).  Renumbered, XCD x runs the pairs p = 8 i + x with all their tiles back to back: one
+// fetch per pair, L2 hits for the rest.  Needs (heads x utterances) % 8 == 0 (else the plain order).  Pure scheduling.
+struct AttnBlock { int tile, h, z; };
+__device__ __forceinline__ AttnBlock attn_block(int xcd_map) {
+  AttnBlock o{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+  if (xcd_map) {
+    const int ntx = gridDim.x, H = gridDim.y;
+    const int lin = blockIdx.x + ntx * (blockIdx.y + H * blockIdx.z);
+    const int xcd = lin & 7, j = lin >> 3;
+    const int pair = (j / ntx) * 8 + xcd;
+    o.tile = j - (j / ntx) * ntx;
+    o.h = pair % H;
+    o.z = pair / H;
+  }
+  return o;
+}
+
 __device__ __forceinline__ uint64_t drop_index(int bh, int N, int q, int key) {
   return ((uint64_t)((size_t)bh * N + q) << 16) | (uint64_t)key;
 }
@@ -66,7 +86,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnArgs a_) {
   if (a.seed_offset) a.seed += *a.seed_offset;
   __shared__ __attribute__((aligned(16))) float Ks[64 * TLD];
   __shared__ __attribute__((aligned(16))) float Vs[64 * TLD];
-  const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const AttnBlock blk = attn_block(a.xcd_map);
+  const int b = a.order ? a.order[blk.z] : blk.z, h = blk.h, q0 = blk.tile * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int len = a.lens[b];
@@ -190,6 +211,7 @@ struct AttnBwdArgs {
   float* delta_out;
   const uint64_t* seed_offset;
   const int* order;                       // as in AttnArgs
+  int xcd_map;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -200,7 +222,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdArgs a
   if (a.seed_offset) a.seed += *a.seed_offset;
   __shared__ __attribute__((aligned(16))) float Ks[64 * TLD];
   __shared__ __attribute__((aligned(16))) float Vs[64 * TLD];
-  const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const AttnBlock blk = attn_block(a.xcd_map);
+  const int b = a.order ? a.order[blk.z] : blk.z, h = blk.h, q0 = blk.tile * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int len = a.lens[b];
@@ -287,7 +310,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwdArgs 
   __shared__ __attribute__((aligned(16))) float Qs[64 * TLD];
   __shared__ __attribute__((aligned(16))) float Gs[64 * TLD];
   __shared__ float lse_s[64], delta_s[64];
-  const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
+  const AttnBlock blk = attn_block(a.xcd_map);
+  const int b = a.order ? a.order[blk.z] : blk.z, h = blk.h, k0 = blk.tile * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int len = a.lens[b];
@@ -519,7 +543,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a_
   if (a.seed_offset) a.seed += *a.seed_offset;
   __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * 128];
-  const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const AttnBlock blk = attn_block(a.xcd_map);
+  const int b = a.order ? a.order[blk.z] : blk.z, h = blk.h, q0 = blk.tile * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int len = a.lens[b];
@@ -647,7 +672,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_bf16_kernel(const AttnBwdA
   if (a.seed_offset) a.seed += *a.seed_offset;
   __shared__ __attribute__((aligned(16))) unsigned char Ks[64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char Vs[64 * 128];
-  const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const AttnBlock blk = attn_block(a.xcd_map);
+  const int b = a.order ? a.order[blk.z] : blk.z, h = blk.h, q0 = blk.tile * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int len = a.lens[b];
@@ -761,7 +787,8 @@ __global__ __launch_bounds__(256, (sizeof(QT) == 2 && sizeof(CT) == 2) ? 3 : 2) 
   __shared__ __attribute__((aligned(16))) unsigned char Qs[64 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char Gs[64 * 128];
   __shared__ __attribute__((aligned(16))) float lse_s[64], delta_s[64];
-  const int b = a.order ? a.order[blockIdx.z] : (int)blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * 64;
+  const AttnBlock blk = attn_block(a.xcd_map);
+  const int b = a.order ? a.order[blk.z] : blk.z, h = blk.h, k0 = blk.tile * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int len = a.lens[b];
@@ -941,7 +968,9 @@ int dx_attention_fwd(const void* qkvv, int ld, const int* lens, void* ctxv, int 
   DX_REQUIRE(lens && ctx && lse && ldc >= D && (ldc % 4) == 0 && ((uintptr_t)ctx % 16) == 0, "dx_attention_fwd: bad output arguments");
   DX_REQUIRE(!ctx_bf16 || (bf16 && (ldc % 8) == 0), "dx_attention_fwd: a 16-bit context needs the 16-bit operand mode and ldc %% 8 == 0");
   DX_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "dx_attention_fwd: dropout p out of range");
-  AttnArgs a{qkv, ld, lens, ctx, ldc, lse, B, N, H, D, seed, (uint32_t)lrintf(p_drop * 65536.f), 1.f / (1.f - p_drop), seed_offset, order};
+  AttnArgs a{qkv, ld, lens, ctx, ldc, lse, B, N, H, D, seed, (uint32_t)lrintf(p_drop * 65536.f), 1.f / (1.f - p_drop), seed_offset, order, 0};
+  static const int xmap_env = getenv("DX_ATTN_XCD") ? atoi(getenv("DX_ATTN_XCD")) : 1;
+  a.xcd_map = xmap_env && ((H * B) % 8 == 0);
   hipStream_t s = (hipStream_t)stream;
   dx_prof_begin(DX_PROF_ATTN_FWD, s);
   const dim3 grid(dx_cdiv(N, 64), H, B);
@@ -971,7 +1000,9 @@ int dx_attention_bwd(const void* qkvv, int ld, const void* ctxv, const void* dct
   const long items = (long)B * N * H;
   if (!bf16)                                       // the bf16 dQ kernel computes delta on the fly and leaves it for dK/dV
     hipLaunchKernelGGL(attn_delta_kernel, dim3((int)std::min<long>((items + 3) / 4, 8192)), dim3(256), 0, s, dctx, ctx, ldc, delta, B, N, H);
-  AttnBwdArgs a{qkv, ld, dctx, ldc, lse, delta, lens, dqkv, ldg, B, N, H, D, seed, (uint32_t)lrintf(p_drop * 65536.f), 1.f / (1.f - p_drop), ctx, delta, seed_offset, order};
+  AttnBwdArgs a{qkv, ld, dctx, ldc, lse, delta, lens, dqkv, ldg, B, N, H, D, seed, (uint32_t)lrintf(p_drop * 65536.f), 1.f / (1.f - p_drop), ctx, delta, seed_offset, order, 0};
+  static const int xmap_env = getenv("DX_ATTN_XCD") ? atoi(getenv("DX_ATTN_XCD")) : 1;
+  a.xcd_map = xmap_env && ((H * B) % 8 == 0);
   dx_prof_begin(DX_PROF_ATTN_BWD, s);
   if (bf16) {
     const dim3 grid(dx_cdiv(N, 64), H, B);

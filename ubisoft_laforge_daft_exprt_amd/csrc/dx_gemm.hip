@@ -677,7 +677,7 @@ __global__ __launch_bounds__(512) void conv_dk_kernel(const ConvGemmArgs a) {
     const int nco = gridDim.y, tpx = gridDim.x >> 3;                  // (the host pads gridDim.x to a multiple of 8)
     const int lin = blockIdx.x + gridDim.x * blockIdx.y;
     const int xcd = lin & 7, j = lin >> 3;
-    const int cg = nco < 4 ? nco : 4;
+    const int cg = nco < a.xcd_swizzle ? nco : a.xcd_swizzle;      // (xcd_swizzle = blocks per group: 4)
     const int per_group = tpx * cg;
     const int grp = j / per_group, rem = j - grp * per_group;
     const int t = rem / cg;
@@ -1010,7 +1010,8 @@ void launch_conv_dk(const ConvGemmArgs& a, hipStream_t s) {
   dim3 grid(a.B * dx_cdiv(a.N, 128), a.CoutP / TILE);
   ConvGemmArgs b = a;
   static const int swz_env = getenv("DX_DK_SWIZZLE") ? atoi(getenv("DX_DK_SWIZZLE")) : 1;
-  b.xcd_swizzle = swz_env && grid.y > 1 && (grid.y <= 4 || grid.y % 4 == 0);
+  b.xcd_swizzle = (swz_env && grid.y > 1 && (grid.y <= 4 || grid.y % 4 == 0)) ? (swz_env == 1 ? 4 : swz_env) : 0;   // DX_DK_SWIZZLE = 8: all blocks of a tile together (diagnostic)
+  if (b.xcd_swizzle && grid.y % b.xcd_swizzle != 0 && grid.y > (unsigned)b.xcd_swizzle) b.xcd_swizzle = 4;
   if (b.xcd_swizzle) grid.x = dx_roundup(grid.x, 8);
   hipLaunchKernelGGL((conv_dk_kernel<TAPS, XH>), grid, dim3(512), smem, s, b);
 }
