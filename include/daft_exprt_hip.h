@@ -80,9 +80,9 @@ int dx_conv_wgrad(const void* dY, int ldy, const void* X, int ldx, float* G,
                   int B, int N, int Cin, int Cout, int taps, const int* lens, int skip_halo,
                   int bf16, int dy_bf16, int x_bf16, float* dbias, void* stream);
 /* dbias (optional, caller-zeroed [Cout]): the bias gradient sum_rows dY is accumulated by the same launch from the staged dY tiles */
-/* Up to 8 weight gradients of one kind (same taps, same operand storage, bf16 / fp16 operand mode, Cin % 128 == 0) in ONE launch:
+/* Up to 32 weight gradients of one kind (same taps, same operand storage, bf16 / fp16 operand mode, Cin % 128 == 0) in ONE launch:
  * the eight k = 3 layers of a 4-block FFT stack fill the chip at a 4-way token split instead of 16-way per layer (a quarter of the fp32
- * atomics).  `jobs` is a HOST array of njobs DxWgradJob (read during the call; the descriptors travel as kernel arguments); every field
+ * atomics); more layers run as further rounds of workgroups of the same launch (their atomic epilogues overlap the next round).  `jobs` is a HOST array of njobs DxWgradJob (read during the call; the descriptors travel as kernel arguments); every field
  * has the meaning of the dx_conv_wgrad argument of the same name. */
 typedef struct DxWgradJob {
   const void* dY; const void* X; float* G; float* dbias; const int* lens;

@@ -1129,6 +1129,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 // barriers and chunk bookkeeping per MFMA: k = 3 launches -2.4 %, k = 1 launches -8 %; 64 for fp32-stored operands with k = 3
 constexpr int wb_bk(int taps, bool dyh, bool xh) { return (taps == 1 || (dyh && xh)) ? 128 : 64; }
 constexpr int WB_LD = 144;     // LDS row stride in bf16 elements (288 B)
+// Rows 8 apart sit on the same banks (8 x 288 B = 9 x 256 B), and the two 16-lane groups of a half-wave read rows 8 apart: a 2-way conflict
+// on every transposed read (tools/ubench/lds_read_patterns.hip: 152 vs 269 B/clk at 8 waves).  So the 64-channel halves of a row are swapped
+// in every second group of eight rows: element (row, c) lives at column c ^ WB_X(row).
+#define WB_X(ROW_) ((((ROW_) >> 3) & 1) << 6)
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 struct WgradBf16Args {
@@ -1145,7 +1149,7 @@ struct WgradBf16Args {
 // of fp32 atomics per layer (~19 us at the memory-side atomic rate) and 128 x 64 tiles that each stage their own dY copy.  Eight layers
 // per launch fill the chip with the wide (128 x 128, one workgroup per CU) tile at a 4-way split: a quarter of the atomics and half the
 // staging per MFMA.  The descriptors travel as kernel arguments (no device-side descriptor table to keep alive or to copy).
-constexpr int WG_MAX_JOBS = 8;
+constexpr int WG_MAX_JOBS = 32;
 struct WgradJobDev {
   const void* dY; const void* X; float* G; float* dbias; const int* lens;
   int ldy, ldx, B, N, Cin, Cout, skip_halo, pad_;
@@ -1154,18 +1158,40 @@ struct WgradBatchArgs {
   WgradJobDev job[WG_MAX_JOBS];
   int ksplit;
   int xcd_group;   // 1: the tiles of one (job, token slice) pair run on ONE XCD (see the kernel); needs gridDim.x == 8 and gridDim.y * gridDim.z % 8 == 0
+  unsigned long long* stamps;   // diagnostic builds (-DDX_WG_STAMPS, tools/wgrad_stamps.py) only: [workgroup][wave][8] s_memtime values / sums
 };
+#ifdef DX_WG_STAMPS
+static unsigned long long* g_wgrad_stamps = nullptr;
+extern "C" void dx_wgrad_set_stamps(unsigned long long* p) { g_wgrad_stamps = p; }
+#define WG_NOW() __builtin_amdgcn_s_memtime()
+#define WG_STAMP(K, V) { if ((tid & 63) == 0 && ba.stamps) ba.stamps[((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + (tid >> 6)) * 8 + (K)] = (V); }
+#else
+#define WG_NOW() 0ull
+#define WG_STAMP(K, V) {}
+#endif
+
+// the same transposed read as inline asm: invisible to hipcc's wait-count pass (callers place `s_waitcnt lgkmcnt` themselves)
+template <int OFF>
+__device__ __forceinline__ s16x4 dx_tr16_b64_asm(unsigned lds_addr) {
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF) : "memory");
+  return v;
+}
 
 __device__ __forceinline__ bf16x8 tr_fragment(const dx_h16* tile, int row0, int col0, int lane) {
   // rows row0 + 8g + [0,8), columns col0 + [0,16): lane (r = lane & 15, g = lane >> 4) gets column r, rows 8g..8g+7
   const int li = lane & 15, g = lane >> 4, q = li >> 2, p = li & 3;
-  const dx_h16* a0 = tile + (row0 + 8 * g + q) * WB_LD + col0 + 4 * p;
+  const int rowA = row0 + 8 * g + q, rowB = rowA + 4;
+  const dx_h16* a0 = tile + rowA * WB_LD + ((col0 + 4 * p) ^ WB_X(rowA));
+  const dx_h16* a1 = tile + rowB * WB_LD + ((col0 + 4 * p) ^ WB_X(rowB));
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * WB_LD));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a1));
   typedef short s16x8 __attribute__((ext_vector_type(8)));
   const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, v);
 }
+
+static __device__ uint4 dx_wgrad_zero_unit[4];      // the source of DMA rows that do not exist (zero-initialised, never written)
 
 // CIW = waves along the input channels: 2 -> 256 threads, 128 co x 64 ci per workgroup, two workgroups per CU;
 //                                      4 -> 512 threads, 128 co x 128 ci, ONE workgroup per CU (Cin % 128 == 0).
@@ -1179,6 +1205,8 @@ __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel
   // the fastest index and workgroups go to the XCDs round-robin), so that operand leaves the memory side eight times (PMC: 2.4x the algorithmic
   // bytes).  Renumbered, XCD x runs the pairs p = 8 i + x with all 8 tiles of a pair: one fetch per pair, seven L2 hits.
   int tile_id = blockIdx.x, job_id = blockIdx.y, split_id = blockIdx.z;
+  [[maybe_unused]] const unsigned long long t_start = WG_NOW();
+  [[maybe_unused]] unsigned long long t_vm = 0, t_bar = 0, n_chunks = 0;
   if (ba.xcd_group) {
     const int lin = blockIdx.x + 8 * (blockIdx.y + gridDim.y * blockIdx.z);
     const int xcd = lin & 7, j = lin >> 3;
@@ -1197,7 +1225,9 @@ __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel
   // wave: 64 co x 32 ci -> 4 x 2 x TAPS MFMA tiles; waves = 2 (co) x CIW (ci).
   // The dY tile and the (halo-extended) X tile are staged once per 64-token chunk and shared by the taps.
   constexpr int PAD = (TAPS - 1) / 2;
-  constexpr int WB_BK = wb_bk(TAPS, DYH, XH);
+  // DMA form (wide tile, both operands stored 16-bit): the tiles go global -> LDS by LDS-DMA loads into a ring of four 64-token images
+  constexpr bool DMA = CIW == 4 && DYH && XH;
+  constexpr int WB_BK = DMA ? 64 : wb_bk(TAPS, DYH, XH);
   constexpr int NT = CIW * 128;
   constexpr int CI_T = CIW * 32;
   constexpr int XROWS = WB_BK + TAPS - 1;
@@ -1207,8 +1237,18 @@ __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel
   constexpr int X_IT = (XROWS * XU + NT - 1) / NT;
   // ONE LDS array: the dY tile, the X tile (rows beyond the halo stay zero so every tr read is in bounds), and - after the chunk
   // loop - the fp32 staging tile of the epilogue
-  constexpr int SMEM_BYTES = (2 * WB_BK + 8) * WB_LD * 2;
-  __shared__ __attribute__((aligned(16))) dx_h16 smem_all[(2 * WB_BK + 8) * WB_LD];
+  // The wide form (one workgroup per CU) keeps TWO images of the pair of tiles and runs a software pipeline over them (see the chunk loop).
+  constexpr bool PIPE = CIW == 4;
+  constexpr int IMG = (2 * WB_BK + 8) * WB_LD;                     // elements per image: dY tile, X tile + 8 zero rows
+  // DMA images: unpadded 256-byte rows (an LDS-DMA wave-instruction writes 1 KB = four rows, lane-linear), XOR-swizzled 16-byte units
+  constexpr int DMA_NIMG = 4, DMA_XG = (WB_BK + TAPS - 1 + 3) / 4;  // X row groups of four per image (k = 3: 17, the last one half halo, half zeros)
+  constexpr int DMA_IMGB = (WB_BK + 4 * DMA_XG + 4) * 256;         // bytes per image (the window reads reach 2 rows past the last group)
+  constexpr int SMEM_BYTES = DMA ? DMA_NIMG * DMA_IMGB : IMG * 2;
+  // ONE __shared__ object (a second one beside an LDS-DMA destination makes hipcc drain the DMA queue before LDS reads): the
+  // per-utterance limits of the chunk walk live in its last 2 KB
+  constexpr int SMEM_ELEMS = DMA ? DMA_NIMG * DMA_IMGB / 2 : (PIPE ? 2 : 1) * IMG;
+  __shared__ __attribute__((aligned(16))) dx_h16 smem_all[SMEM_ELEMS + 1024];
+  int* const limit_s = reinterpret_cast<int*>(smem_all + SMEM_ELEMS);
   dx_h16* const Ds = smem_all;
   dx_h16* const Xs = smem_all + WB_BK * WB_LD;
   const int ci_tiles = (a.Cin + CI_T - 1) / CI_T;
@@ -1227,7 +1267,15 @@ __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int u = tid; u < 8 * WB_LD; u += NT) Xs[WB_BK * WB_LD + u] = (dx_h16)0.f;
+  if constexpr (DMA) {                     // the rows behind the last X group of every image stay zero
+    for (int u = tid; u < DMA_NIMG * 4 * 128; u += NT)
+      reinterpret_cast<dx_h16*>(reinterpret_cast<char*>(smem_all) + (u / 512) * DMA_IMGB + (WB_BK + 4 * DMA_XG) * 256)[u % 512] = (dx_h16)0.f;
+  } else {
+    for (int u = tid; u < 8 * WB_LD; u += NT) {
+      Xs[WB_BK * WB_LD + u] = (dx_h16)0.f;
+      if constexpr (PIPE) Xs[IMG + WB_BK * WB_LD + u] = (dx_h16)0.f;
+    }
+  }
 
   // Fused bias gradient (column sums of the dY tile), done by the workgroups of input-channel tile 0 with ALL their threads
   // (thread = channel pair x one slice of the rows, 4-byte LDS reads).  As 128 threads x 64 two-byte reads it made those
@@ -1238,21 +1286,14 @@ __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel
   f32x4 dreg[D_IT], xreg[X_IT];
   // Staging addresses: (unit -> tile row, channel) is fixed per thread, only the chunk's first row moves: a wave-uniform 64-bit
   // chunk base (scalar unit) plus a 32-bit per-thread constant.
-  int drow[D_IT], dtoff[D_IT], xrow[X_IT], xtoff[X_IT];
-#pragma unroll
-  for (int it = 0; it < D_IT; ++it) {
-    const int u = tid + it * NT;
-    const int row = u / DU, c = co0 + (u % DU) * DE;
-    drow[it] = c < a.Cout ? row : 0x40000000;           // channel out of range: never in bounds
-    dtoff[it] = row * a.ldy + c;
-  }
-#pragma unroll
-  for (int it = 0; it < X_IT; ++it) {
-    const int u = tid + it * NT;
-    const int row = u / XU, c = ci0 + (u % XU) * XE;
-    xrow[it] = (u < XROWS * XU && c < a.Cin) ? row : 0x40000000;
-    xtoff[it] = row * a.ldx + c;
-  }
+  // A thread's units keep their channel from one iteration to the next (NT % DU == 0): the tile row advances by NT / DU, so ONE row, ONE
+  // 32-bit offset per operand and scalar multiples of the leading dimension are all the addressing state (18 registers as arrays).
+  static_assert(NT % DU == 0 && NT % XU == 0, "staging units");
+  constexpr int DSTEP = NT / DU, XSTEP = NT / XU;
+  const int dch = co0 + (tid % DU) * DE, xch = ci0 + (tid % XU) * XE;
+  const int drow0 = dch < a.Cout ? tid / DU : 0x40000000;            // channel out of range: never in bounds
+  const int xrow0 = xch < a.Cin ? tid / XU : 0x40000000;
+  const int dtoff0 = (tid / DU) * a.ldy + dch, xtoff0 = (tid / XU) * a.ldx + xch;
 #define DX_WG_LOAD(B_, NC_)                                                                                                   \
   {                                                                                                                           \
     const ptrdiff_t dbase_ = ((ptrdiff_t)(B_) * a.N + (NC_)) * a.ldy;                                                         \
@@ -1260,42 +1301,46 @@ __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel
     const int dlim_ = a.N - (NC_), xlo_ = PAD - (NC_), xhi_ = a.N - (NC_) + PAD;                                              \
     _Pragma("unroll") for (int it = 0; it < D_IT; ++it) {                                                                     \
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                                                    \
-      if (drow[it] < dlim_) {                                                                                                 \
-        if constexpr (DYH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const dx_h16*>(a.dY) + dbase_ + dtoff[it]);   \
-        else v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.dY) + dbase_ + dtoff[it]);                  \
+      if (drow0 + it * DSTEP < dlim_) {                                                                                       \
+        const ptrdiff_t o_ = dbase_ + (ptrdiff_t)(it * DSTEP) * a.ldy;                                                        \
+        if constexpr (DYH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const dx_h16*>(a.dY) + o_ + dtoff0);          \
+        else v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.dY) + o_ + dtoff0);                         \
       }                                                                                                                       \
       dreg[it] = v;                                                                                                           \
     }                                                                                                                         \
     _Pragma("unroll") for (int it = 0; it < X_IT; ++it) {                                                                     \
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};                                                                                    \
-      if (xrow[it] >= xlo_ && xrow[it] < xhi_) {                                                                              \
-        if constexpr (XH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const dx_h16*>(a.X) + xbase_ + xtoff[it]);     \
-        else v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.X) + xbase_ + xtoff[it]);                   \
+      const int xr_ = xrow0 + it * XSTEP;                                                                                     \
+      if (xr_ >= xlo_ && xr_ < xhi_ && xr_ < XROWS) {                                                                         \
+        const ptrdiff_t o_ = xbase_ + (ptrdiff_t)(it * XSTEP) * a.ldx;                                                        \
+        if constexpr (XH) v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const dx_h16*>(a.X) + o_ + xtoff0);            \
+        else v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.X) + o_ + xtoff0);                          \
       }                                                                                                                       \
       xreg[it] = v;                                                                                                           \
     }                                                                                                                         \
   }
-#define DX_WG_STORE()                                                                                                         \
+#define DX_WG_STORE(IMG_OFF_)                                                                                                 \
   {                                                                                                                           \
+    dx_h16* const dsw_ = Ds + (IMG_OFF_);                                                                                     \
+    dx_h16* const xsw_ = Xs + (IMG_OFF_);                                                                                     \
     _Pragma("unroll") for (int it = 0; it < D_IT; ++it) {                                                                     \
       const int u = tid + it * NT;                                                                                           \
       const int row = u / DU, q = u % DU;                                                                                     \
-      if constexpr (DYH) *reinterpret_cast<f32x4*>(Ds + row * WB_LD + q * 8) = dreg[it];                                      \
-      else *reinterpret_cast<uint2*>(Ds + row * WB_LD + q * 4) = pack_bf16x4v(dreg[it]);                                      \
+      if constexpr (DYH) *reinterpret_cast<f32x4*>(dsw_ + row * WB_LD + ((q * 8) ^ WB_X(row))) = dreg[it];                    \
+      else *reinterpret_cast<uint2*>(dsw_ + row * WB_LD + ((q * 4) ^ WB_X(row))) = pack_bf16x4v(dreg[it]);                    \
     }                                                                                                                         \
     _Pragma("unroll") for (int it = 0; it < X_IT; ++it) {                                                                     \
       const int u = tid + it * NT;                                                                                           \
       const int row = u / XU, q = u % XU;                                                                                     \
       if (u < XROWS * XU) {                                                                                                   \
-        if constexpr (XH) *reinterpret_cast<f32x4*>(Xs + row * WB_LD + q * 8) = xreg[it];                                     \
-        else *reinterpret_cast<uint2*>(Xs + row * WB_LD + q * 4) = pack_bf16x4v(xreg[it]);                                    \
+        if constexpr (XH) *reinterpret_cast<f32x4*>(xsw_ + row * WB_LD + ((q * 8) ^ WB_X(row))) = xreg[it];                   \
+        else *reinterpret_cast<uint2*>(xsw_ + row * WB_LD + ((q * 4) ^ WB_X(row))) = pack_bf16x4v(xreg[it]);                  \
       }                                                                                                                       \
     }                                                                                                                         \
   }
 
   // chunk walk of this split-K slice (interleaved: every slice sees a mix of utterance lengths).  The per-utterance limits sit in
   // LDS and (b, chunk-in-row) advance incrementally: a scalar global load + an integer division per chunk cost ~2 k cycles here.
-  __shared__ int limit_s[512];
   for (int i = tid; i < min(a.B, 512); i += NT) limit_s[i] = a.skip_halo >= 0 ? a.lens[i] + a.skip_halo : 0x7fffffff;
   __syncthreads();
   const int step_b = a.ksplit / chunks_per_row, step_k = a.ksplit - step_b * chunks_per_row;
@@ -1306,19 +1351,367 @@ __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel
     return nc < (b < 512 ? limit_s[b] : (a.skip_halo >= 0 ? a.lens[b] + a.skip_halo : 0x7fffffff));
   };
   while (c < total && !live()) advance();
-  if (c < total) DX_WG_LOAD(b, nc);
+  if constexpr (!DMA) if (c < total) DX_WG_LOAD(b, nc);
+#ifndef DX_WG_ABL
+#define DX_WG_ABL 0      // timing ablations (tools/ablation_build.py): 1 no MFMA, 2 no global loads in the loop, 4 tiles staged once
+#endif
+  if constexpr (DMA) {
+    // ---- LDS-DMA ring -------------------------------------------------------------------------------------------------------------
+    // Measured on the serial form (tools/microbench_wgrad.py, ablation builds, eight k = 3 jobs of the frame-level decoder): 277 us as it
+    // stood, 218 without the global loads, 191 without the MFMAs, 103 with neither; this launch moves 509 MB for 177 GFLOP, i.e. it is
+    // HBM-bound at its best (110 us at the 4.6 TB/s the load path reaches alone) and was running memory time + matrix time + epilogue.
+    // A register-staged double-buffered pipeline did not fit (96 accumulators + 36 staging + 56 fragment registers spill, and a scratch
+    // reload drains the whole load queue: stamped, tools/wgrad_stamps.py).  So the tiles never touch registers: every wave issues four
+    // (wave 0: five) `global_load_lds_dwordx4` per 64-token chunk, each writing four 256-byte rows of an image; THREE chunks are in
+    // flight while the fourth image is multiplied; counted `s_waitcnt vmcnt` + a raw barrier per chunk (a `__syncthreads()` would drain
+    // the queue).  Rows that do not exist (utterance ends, halo) read a zero unit instead.  The image is unpadded, so the 16-byte units
+    // of a row are XOR-swizzled by (row & 3) << 2 on the SOURCE side: the transposed fragment reads of four consecutive rows then hit
+    // disjoint banks.  Fragments: K step ks + 1 is read before the MFMAs of step ks are issued (two register sets); the three taps of
+    // an X fragment come from ONE 12-token window (three reads + four v_alignbit instead of six reads).
+    constexpr int NKS = WB_BK / 32;                               // 2
+    constexpr int XW = TAPS == 3 ? 3 : 2;
+    static_assert(NKS == 2, "DMA ring: two K steps per chunk");
+    // hipcc treats an LDS-DMA in flight as a pending write to ALL of LDS: any LDS read it can see gets an `s_waitcnt vmcnt(0)` in front
+    // (seen in the ISA of a first version with the builtin transposed reads: the ring drained every chunk).  So inside the loop the
+    // compiler sees NO LDS access: the fragment reads are inline asm with hand-placed lgkmcnt waits (the wait asm ties the fragment
+    // registers, so no MFMA can be scheduled above it), the chunk walk reads lens[] through the scalar cache, and the bias gradient is
+    // one more MFMA column (dY fragments x a vector of ones) instead of LDS column sums.
+    struct Frags { s16x4 v[8 + 2 * XW]; };                        // dY (i, h) -> v[2 i + h]; X window (j, h) -> v[8 + XW j + h]
+    Frags F[2];
+    char* const smem_b = reinterpret_cast<char*>(smem_all);
+    const unsigned smem_a = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem_b);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int li = lane & 15, fq = li >> 2, fp = li & 3;
+    const int rowoff = (8 * g + fq) * 256 + (fp & 1) * 8;
+    // Byte addresses inside image 0.  Swizzle: unit' = unit ^ ((row & 3) << 2) ^ (((row >> 3) & 1) << 1).  The first term spreads the four
+    // rows of a 16-lane transposed read over disjoint banks; the second gives the two 16-lane groups of a half-wave (rows 8 apart: the
+    // same banks in a 256-byte-row image) complementary halves of the bank row - without it the fragment reads ran at ~80 B/clk (2-way
+    // conflict, measured: the reads alone took as long as the MFMAs).  Fragment rows are 32 ks + 8 g + q + 4 h: (row >> 3) & 1 = g & 1,
+    // except for the third window read (h = 2), which belongs to the next group of eight.
+    const int gb = g & 1;
+    unsigned dA[4], xA[2], xA2[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dA[i] = smem_a + rowoff + (((wc * 8 + i * 2 + (fp >> 1)) ^ (fq << 2) ^ (gb << 1)) << 4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      xA[j] = smem_a + WB_BK * 256 + rowoff + (((wt * 4 + j * 2 + (fp >> 1)) ^ (fq << 2) ^ (gb << 1)) << 4);
+      xA2[j] = smem_a + WB_BK * 256 + rowoff + (((wt * 4 + j * 2 + (fp >> 1)) ^ (fq << 2) ^ ((gb ^ 1) << 1)) << 4);
+    }
+#define DX_RD(F_, SLOT_, ADR_, OFF_) F_.v[SLOT_] = dx_tr16_b64_asm<(OFF_)>(ADR_);
+#define DX_READ_FRAGS(F_, IMG_, KS_)                                                                                          \
+  {                                                                                                                           \
+    const unsigned o_ = (unsigned)((IMG_) * DMA_IMGB);                                                                        \
+    DX_RD(F_, 0, dA[0] + o_, ((KS_) * 32) * 256) DX_RD(F_, 1, dA[0] + o_, ((KS_) * 32 + 4) * 256)                             \
+    DX_RD(F_, 2, dA[1] + o_, ((KS_) * 32) * 256) DX_RD(F_, 3, dA[1] + o_, ((KS_) * 32 + 4) * 256)                             \
+    DX_RD(F_, 4, dA[2] + o_, ((KS_) * 32) * 256) DX_RD(F_, 5, dA[2] + o_, ((KS_) * 32 + 4) * 256)                             \
+    DX_RD(F_, 6, dA[3] + o_, ((KS_) * 32) * 256) DX_RD(F_, 7, dA[3] + o_, ((KS_) * 32 + 4) * 256)                             \
+    DX_RD(F_, 8, xA[0] + o_, ((KS_) * 32) * 256) DX_RD(F_, 9, xA[0] + o_, ((KS_) * 32 + 4) * 256)                             \
+    if constexpr (XW == 3) DX_RD(F_, 10, xA2[0] + o_, ((KS_) * 32 + 8) * 256)                                                 \
+    DX_RD(F_, 8 + XW, xA[1] + o_, ((KS_) * 32) * 256) DX_RD(F_, 9 + XW, xA[1] + o_, ((KS_) * 32 + 4) * 256)                   \
+    if constexpr (XW == 3) DX_RD(F_, 10 + XW, xA2[1] + o_, ((KS_) * 32 + 8) * 256)                                            \
+  }
+    // every fragment of the set has landed; ties the registers so that their consumers stay below
+    auto landed = [&](Frags& f) {
+      if constexpr (XW == 3)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.v[0]), "+v"(f.v[1]), "+v"(f.v[2]), "+v"(f.v[3]), "+v"(f.v[4]), "+v"(f.v[5]), "+v"(f.v[6]), "+v"(f.v[7]),
+                     "+v"(f.v[8]), "+v"(f.v[9]), "+v"(f.v[10]), "+v"(f.v[11]), "+v"(f.v[12]), "+v"(f.v[13]) : : "memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.v[0]), "+v"(f.v[1]), "+v"(f.v[2]), "+v"(f.v[3]), "+v"(f.v[4]), "+v"(f.v[5]), "+v"(f.v[6]), "+v"(f.v[7]),
+                     "+v"(f.v[8]), "+v"(f.v[9]), "+v"(f.v[10]), "+v"(f.v[11]) : : "memory");
+    };
+    f32x4 accb[4];                                                // bias gradient: dY fragment x ones, the waves of input-channel slice 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool bias_wave = do_bias && __builtin_amdgcn_readfirstlane(wt) == 0;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (dx_h16)1.0f;
+    auto multiply = [&](const Frags& f) {
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      typedef int i32x2 __attribute__((ext_vector_type(2)));
+      typedef int i32x4 __attribute__((ext_vector_type(4)));
+      bf16x8 df[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const s16x4 lo = f.v[2 * i], hi = f.v[2 * i + 1];
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        df[i] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        bf16x8 xf[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          // window dwords w0..w4 = tokens (0,1) (2,3) (4,5) (6,7) (8,9) of this lane's channel
+          const i32x2 a0 = __builtin_bit_cast(i32x2, f.v[8 + XW * j]), a1 = __builtin_bit_cast(i32x2, f.v[9 + XW * j]);
+          int w[5] = {a0[0], a0[1], a1[0], a1[1], 0};
+          if constexpr (TAPS == 3) w[4] = __builtin_bit_cast(i32x2, f.v[8 + XW * j + XW - 1])[0];
+          i32x4 o;
+          if (t == 0) o = i32x4{w[0], w[1], w[2], w[3]};
+          else if (t == 2) o = i32x4{w[1], w[2], w[3], w[4]};
+          else o = i32x4{(int)__builtin_amdgcn_alignbit((unsigned)w[1], (unsigned)w[0], 16), (int)__builtin_amdgcn_alignbit((unsigned)w[2], (unsigned)w[1], 16),
+                         (int)__builtin_amdgcn_alignbit((unsigned)w[3], (unsigned)w[2], 16), (int)__builtin_amdgcn_alignbit((unsigned)w[4], (unsigned)w[3], 16)};
+          xf[j] = __builtin_bit_cast(bf16x8, o);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if (DX_WG_ABL & 1) asm volatile("" :: "v"(df[i]), "v"(xf[j]));
+            else acc[t][i][j] = DX_MFMA_H16(df[i], xf[j], acc[t][i][j]);
+          }
+      }
+      if (bias_wave) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accb[i] = DX_MFMA_H16(df[i], ones, accb[i]);
+      }
+    };
+    // DMA source addressing: lane -> (row in the group of four, unit of the row); the unit index is swizzled on the source side
+    const int srow = lane >> 4, sunit = (lane & 15) ^ (srow << 2) ^ (((wave_u >> 1) & 1) << 1);     // this wave's groups: wave + 8 k, rows 4 * group + srow
+    const bool dch_ok = co0 + sunit * 8 < a.Cout, xch_ok = ci0 + sunit * 8 < a.Cin;
+    const int dsoff = srow * a.ldy + co0 + sunit * 8, xsoff = srow * a.ldx + ci0 + sunit * 8;     // elements
+    const dx_h16* const zero_src = reinterpret_cast<const dx_h16*>(dx_wgrad_zero_unit);
+    auto issue = [&](int img, int bb, int nn) {
+      const dx_h16* const dsrc = reinterpret_cast<const dx_h16*>(a.dY) + ((ptrdiff_t)bb * a.N + nn) * a.ldy;
+      const dx_h16* const xsrc = reinterpret_cast<const dx_h16*>(a.X) + ((ptrdiff_t)bb * a.N + nn - PAD) * a.ldx;
+      const int dlim = a.N - nn, xlo = PAD - nn, xhi = min(a.N - nn + PAD, WB_BK + TAPS - 1);
+      char* const ibase = smem_b + img * DMA_IMGB;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int grp = wave_u + 8 * k, row = 4 * grp + srow;
+        const dx_h16* src = (dch_ok && row < dlim) ? dsrc + (ptrdiff_t)(4 * grp) * a.ldy + dsoff : zero_src;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(ibase + grp * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int grp = wave_u + 8 * k;
+        if (grp < DMA_XG) {                                       // wave-uniform: k = 2 is wave 0's (k = 3 layers)
+          const int row = 4 * grp + srow;
+          const dx_h16* src = (xch_ok && row >= xlo && row < xhi) ? xsrc + (ptrdiff_t)(4 * grp) * a.ldx + xsoff : zero_src;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(ibase + WB_BK * 256 + grp * 1024), 16, 0, 0);
+        }
+      }
+    };
+    // this wave's DMA instructions per chunk: 4, or 5 for wave 0 of a k = 3 layer; `ahead` chunks may stay in flight
+    auto wait_dma = [&](int ahead) {
+      if (DMA_XG > 16 && wave_u == 0) {
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    };
+    // the chunk walk of this form: limits through the scalar cache (no LDS read the compiler can see, see above)
+    auto live_s = [&]() {
+      b = __builtin_amdgcn_readfirstlane(b); kc = __builtin_amdgcn_readfirstlane(kc); c = __builtin_amdgcn_readfirstlane(c);   // provably uniform: s_load, scalar branch
+      nc = kc * WB_BK;
+      if (a.skip_halo < 0) return true;
+      int len;                               // hipcc will not use the scalar cache by itself here (the kernel's atomics may alias lens[])
+      asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(len) : "s"(a.lens + b) : "memory");
+      return nc < len + a.skip_halo;
+    };
+    while (c < total && !live_s()) advance();
+    { WG_STAMP(0, t_start) WG_STAMP(1, WG_NOW()) }
+#ifdef DX_WG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stamp stores must not sit in the counted DMA queue
+#endif
+    int issued = 0, done = 0;
+#pragma unroll 1
+    for (int k = 0; k < DMA_NIMG - 1 && c < total; ++k) {
+      issue(k, b, nc);
+      ++issued;
+      advance();
+      while (c < total && !live_s()) advance();
+    }
+    if (issued) {
+      wait_dma(issued - 1);
+      __builtin_amdgcn_s_barrier();
+      DX_READ_FRAGS(F[0], 0, 0)
+    }
+#pragma unroll 1
+    while (done < issued) {
+      const int img = done & (DMA_NIMG - 1);
+      if (c < total) {                       // image (done + 3) & 3 was last read before the barrier of the previous iteration
+        if (!(DX_WG_ABL & 2)) issue((done + DMA_NIMG - 1) & (DMA_NIMG - 1), b, nc);
+        ++issued;
+        advance();
+        while (c < total && !live_s()) advance();
+      }
+      landed(F[0]);                          // read a whole multiply ago (and drains the walk's scalar loads)
+      DX_READ_FRAGS(F[1], img, 1)
+      multiply(F[0]);
+      const bool more = done + 1 < issued;
+#ifdef DX_WG_STAMPS
+      const unsigned long long tv0 = WG_NOW();
+#endif
+      if (more && !(DX_WG_ABL & 2)) wait_dma(issued - done - 2);
+#ifdef DX_WG_STAMPS
+      const unsigned long long tb0 = WG_NOW();
+      t_vm += tb0 - tv0;
+#endif
+      landed(F[1]);
+      __builtin_amdgcn_s_barrier();          // chunk done + 1 is complete in LDS; nobody reads image img any more
+#ifdef DX_WG_STAMPS
+      t_bar += WG_NOW() - tb0; ++n_chunks;
+#endif
+      if (more) DX_READ_FRAGS(F[0], (done + 1) & (DMA_NIMG - 1), 0)
+      multiply(F[1]);
+      ++done;
+    }
+#undef DX_RD
+#undef DX_READ_FRAGS
+    if (bias_wave) {                         // lanes of output column 0 hold the sums of rows 4 g + e
+      if (r == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int co = co0 + wc * 64 + i * 16 + g * 4 + e;
+            if (co < a.Cout && accb[i][e] != 0.f) atomicAdd(&a.dbias[co], accb[i][e]);
+          }
+      }
+    }
+    __syncthreads();                         // every DMA was waited for above: the epilogue may reuse the images
+    WG_STAMP(2, WG_NOW()) WG_STAMP(4, t_vm) WG_STAMP(5, t_bar) WG_STAMP(6, n_chunks)
+  } else if constexpr (PIPE) {
+    // Software pipeline over two LDS images, ONE barrier per chunk.  The serial form below (stage, barrier, read fragments, multiply,
+    // barrier) measured, on the eight k = 3 jobs of the frame-level decoder: 279 us as it stands, 185 without the MFMAs, 175 without the
+    // global loads and the staging, 100 with neither - i.e. the three parts ran one AFTER the other (ablation builds, tools/microbench_wgrad.py).
+    // Here, while chunk n is multiplied out of image p: the fragments of K step ks + 1 are read before the MFMAs of step ks are issued
+    // (two fragment sets in registers); chunk n + 1 (in the staging registers since the previous iteration) is stored into image p ^ 1
+    // after the first K step and the global loads of chunk n + 2 are issued behind it (a full chunk of cover); the barrier sits before
+    // the LAST K step's MFMAs, so the first fragments of chunk n + 1 are read under them.
+    // LDS reads: the three taps of an X fragment are the SAME 8 + 2 tokens of a channel shifted by one - one 12-token window (three
+    // transposed reads) and four v_alignbit per fragment instead of six reads: 14 instead of 20 reads per 24 MFMAs (the LDS read
+    // pipe, 128 B/clk for these reads, is as long as the MFMA time in the serial form).
+    constexpr int NKS = WB_BK / 32;
+    constexpr int XW = TAPS == 3 ? 3 : 2;                         // transposed 4-token reads per X fragment window
+    struct Frags { s16x4 d[4][2]; s16x4 x[2][XW]; };
+    Frags F[2];
+    const int li = lane & 15, fq = li >> 2, fp = li & 3;
+    const int lane_off = (8 * g + fq) * WB_LD + 4 * fp;
+    const int gx = (g & 1) << 6;                                  // WB_X of this lane's rows 32 ks + 8 g + fq + {0, 4}; the third window read (+ 8) is in the next group of eight
+    const dx_h16* const dbase = Ds + lane_off + ((wc * 64) ^ gx);
+    const dx_h16* const xbase = Xs + lane_off + ((wt * 32) ^ gx);
+    const dx_h16* const xbase2 = Xs + lane_off + ((wt * 32) ^ gx ^ 64);
+    auto tr4 = [](const dx_h16* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p)); };
+    auto read_frags = [&](int img_off, int ks, Frags& f) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) f.d[i][h] = tr4(dbase + img_off + (ks * 32 + 4 * h) * WB_LD + i * 16);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int h = 0; h < XW; ++h) f.x[j][h] = tr4((h == 2 ? xbase2 : xbase) + img_off + (ks * 32 + 4 * h) * WB_LD + j * 16);
+    };
+    auto multiply = [&](const Frags& f) {
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      typedef int i32x2 __attribute__((ext_vector_type(2)));
+      bf16x8 df[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const s16x8 v = {f.d[i][0][0], f.d[i][0][1], f.d[i][0][2], f.d[i][0][3], f.d[i][1][0], f.d[i][1][1], f.d[i][1][2], f.d[i][1][3]};
+        df[i] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        bf16x8 xf[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          // window dwords w0..w5 = tokens (0,1) (2,3) (4,5) (6,7) (8,9) (10,11) of this lane's channel
+          const i32x2 a0 = __builtin_bit_cast(i32x2, f.x[j][0]), a1 = __builtin_bit_cast(i32x2, f.x[j][1]);
+          int w[5] = {a0[0], a0[1], a1[0], a1[1], 0};
+          if constexpr (TAPS == 3) w[4] = __builtin_bit_cast(i32x2, f.x[j][2])[0];
+          typedef int i32x4 __attribute__((ext_vector_type(4)));
+          i32x4 o;
+          if (t == 0) o = i32x4{w[0], w[1], w[2], w[3]};
+          else if (t == 2) o = i32x4{w[1], w[2], w[3], w[4]};
+          else o = i32x4{(int)__builtin_amdgcn_alignbit((unsigned)w[1], (unsigned)w[0], 16), (int)__builtin_amdgcn_alignbit((unsigned)w[2], (unsigned)w[1], 16),
+                         (int)__builtin_amdgcn_alignbit((unsigned)w[3], (unsigned)w[2], 16), (int)__builtin_amdgcn_alignbit((unsigned)w[4], (unsigned)w[3], 16)};
+          xf[j] = __builtin_bit_cast(bf16x8, o);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if (DX_WG_ABL & 1) asm volatile("" :: "v"(df[i]), "v"(xf[j]));
+            else acc[t][i][j] = DX_MFMA_H16(df[i], xf[j], acc[t][i][j]);
+          }
+      }
+    };
+    bool have = c < total;                 // a chunk is in the staging registers
+    if (have) {
+      DX_WG_STORE(0);
+      advance();
+      while (c < total && !live()) advance();
+      if (c < total) DX_WG_LOAD(b, nc);
+      __syncthreads();
+      read_frags(0, 0, F[0]);
+    }
+    int img = 0;                           // element offset of the image being multiplied
+    { [[maybe_unused]] const int tid = threadIdx.x; WG_STAMP(0, t_start) WG_STAMP(1, WG_NOW()) }
+    while (have) {
+      const bool next = c < total;         // the staging registers hold (or wait for) the chunk after this one
+      if (do_bias) {
+        const int r0b = (tid >> 6) * (WB_BK / (NT / 64));
+        const dx_h16* col = Ds + img + r0b * WB_LD;
+#pragma unroll
+        for (int k = 0; k < WB_BK / (NT / 64); ++k) {
+          const unsigned v = *reinterpret_cast<const unsigned*>(col + k * WB_LD + (((tid & 63) * 2) ^ WB_X(r0b + k)));
+          bsum0 += (float)__builtin_bit_cast(dx_h16, (unsigned short)(v & 0xffffu));
+          bsum1 += (float)__builtin_bit_cast(dx_h16, (unsigned short)(v >> 16));
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        if (ks + 1 < NKS) read_frags(img, ks + 1, F[(ks + 1) & 1]);
+        else {
+#ifdef DX_WG_STAMPS
+          const unsigned long long tb0 = WG_NOW();
+#endif
+          __syncthreads();                 // image img ^ 1 is complete; nobody reads image img any more (the last fragments are in registers)
+#ifdef DX_WG_STAMPS
+          t_bar += WG_NOW() - tb0; ++n_chunks;
+#endif
+          if (next) read_frags(IMG - img, 0, F[0]);
+        }
+        if (ks == (NKS == 4 ? 1 : 0) && next) {
+#ifdef DX_WG_STAMPS
+          { const unsigned long long tv0 = WG_NOW(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_vm += WG_NOW() - tv0; }
+#endif
+          if (!(DX_WG_ABL & 4)) DX_WG_STORE(IMG - img);
+          advance();
+          while (c < total && !live()) advance();
+          if (!(DX_WG_ABL & 2)) if (c < total) DX_WG_LOAD(b, nc);
+        }
+        multiply(F[ks & 1]);
+      }
+      have = next;
+      img = IMG - img;
+    }
+    WG_STAMP(2, WG_NOW()) WG_STAMP(4, t_vm) WG_STAMP(5, t_bar) WG_STAMP(6, n_chunks)
+  } else {
+  [[maybe_unused]] bool first_chunk = true;
   while (c < total) {
-    __syncthreads();
-    DX_WG_STORE();
-    __syncthreads();
+    if (!(DX_WG_ABL & 4) || first_chunk) {
+      __syncthreads();
+      DX_WG_STORE(0);
+      __syncthreads();
+    }
+    first_chunk = false;
     advance();
     while (c < total && !live()) advance();
-    if (c < total) DX_WG_LOAD(b, nc);
+    if (!(DX_WG_ABL & 2)) if (c < total) DX_WG_LOAD(b, nc);
     if (do_bias) {
-      const dx_h16* col = Ds + (tid >> 6) * (WB_BK / (NT / 64)) * WB_LD + (tid & 63) * 2;
+      const int r0b = (tid >> 6) * (WB_BK / (NT / 64));
+      const dx_h16* col = Ds + r0b * WB_LD;
 #pragma unroll
       for (int k = 0; k < WB_BK / (NT / 64); ++k) {
-        const unsigned v = *reinterpret_cast<const unsigned*>(col + k * WB_LD);
+        const unsigned v = *reinterpret_cast<const unsigned*>(col + k * WB_LD + (((tid & 63) * 2) ^ WB_X(r0b + k)));
         bsum0 += (float)__builtin_bit_cast(dx_h16, (unsigned short)(v & 0xffffu));
         bsum1 += (float)__builtin_bit_cast(dx_h16, (unsigned short)(v >> 16));
       }
@@ -1336,9 +1729,13 @@ __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[t][i][j] = DX_MFMA_H16(df[i], xf[j], acc[t][i][j]);
+          for (int j = 0; j < 2; ++j) {
+            if (DX_WG_ABL & 1) asm volatile("" :: "v"(df[i]), "v"(xf[j]));
+            else acc[t][i][j] = DX_MFMA_H16(df[i], xf[j], acc[t][i][j]);
+          }
       }
     }
+  }
   }
 #undef DX_WG_LOAD
 #undef DX_WG_STORE
@@ -1389,7 +1786,7 @@ __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel
       }
     }
   }
-  if (do_bias) {                                         // workgroup-uniform: fold the row slices, one atomic per channel
+  if (do_bias && !DMA) {                                 // workgroup-uniform: fold the row slices, one atomic per channel
     float* red = reinterpret_cast<float*>(Ds);           // the chunk loop and the staging passes are over
     __syncthreads();
     red[(tid >> 6) * TILE + (tid & 63) * 2] = bsum0;
@@ -1402,6 +1799,10 @@ __global__ __launch_bounds__(CIW * 128, CIW == 2 ? 2 : 1) void wgrad_bf16_kernel
       if (t != 0.f) atomicAdd(&a.dbias[co0 + tid], t);
     }
   }
+#ifdef DX_WG_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WG_STAMP(3, WG_NOW())
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1801,12 +2202,18 @@ int dx_conv_wgrad_batched(const void* jobs_, int njobs, int taps, int dy_bf16, i
     tile_jobs += t;
     min_chunks = std::min(min_chunks, j.B * dx_cdiv(j.N, wb_bk(taps, dy_bf16 != 0, x_bf16 != 0)));
   }
-  static const int target = getenv("DX_WGRAD_BLOCKS_BATCH") ? atoi(getenv("DX_WGRAD_BLOCKS_BATCH")) : 256;     // one 512-thread workgroup per CU
-  a.ksplit = std::max(1, std::min(min_chunks, dx_cdiv(target, tile_jobs)));
+  // One 512-thread workgroup per CU and round; a launch of many layers runs several rounds (24 layers: 768 workgroups at the same 4-way
+  // split), so the atomic epilogues of the early finishers run under the chunk loops of the next round instead of at the end of a launch.
+  static const int per_round = getenv("DX_WGRAD_BLOCKS_BATCH") ? atoi(getenv("DX_WGRAD_BLOCKS_BATCH")) : 256;
+  const int rounds = std::max(1, (tile_jobs * 4 + per_round / 2) / per_round);
+  a.ksplit = std::max(1, std::min(min_chunks, rounds * per_round / tile_jobs));
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(tiles, njobs, a.ksplit);
   static const int grp_env = getenv("DX_WGRAD_XCD_GROUP") ? atoi(getenv("DX_WGRAD_XCD_GROUP")) : 1;
   a.xcd_group = grp_env && tiles == 8 && (njobs * a.ksplit) % 8 == 0;
+#ifdef DX_WG_STAMPS
+  a.stamps = g_wgrad_stamps;
+#endif
   dx_prof_begin(DX_PROF_WGRAD_GEMM, s);
 #define DX_WG_LAUNCH(TAPS_)                                                                                            \
   if (dy_bf16 && x_bf16) hipLaunchKernelGGL((wgrad_bf16_kernel<TAPS_, true, true, 4>), grid, dim3(512), 0, s, a);     \

@@ -488,7 +488,9 @@ class _WgradJob(ctypes.Structure):          # DxWgradJob of include/daft_exprt_h
                [(n, ctypes.c_int) for n in ('ldy', 'ldx', 'B', 'N', 'Cin', 'Cout', 'skip_halo', 'reserved')]
 
 
-WGRAD_BATCH = 8
+# layers per dx_conv_wgrad_batched launch (the library takes up to 32), by kernel size.  Measured in the C2 step: the k = 1 layers gain from
+# one launch for all of them (4 launches 243 us -> 2 launches 172 us), the k = 3 layers do not (8 per launch: 668 us, 24 per launch: 687 us)
+WGRAD_BATCH = {1: int(os.environ.get('DX_WGRAD_BATCH_K1', '32')), 3: int(os.environ.get('DX_WGRAD_BATCH_K3', '8'))}
 WGRAD_BATCH_LOG = {}
 
 
@@ -498,8 +500,9 @@ def flush_wgrads(rt) -> int:
     the gradients (the gradient exchange, the optimiser)."""
     launches = 0
     for (taps, dyh, xh, prec), jobs in rt.wgrad_queue.items():
-        for i in range(0, len(jobs), WGRAD_BATCH):
-            part = jobs[i:i + WGRAD_BATCH]
+        jobs.sort(key=lambda j: -j[0][7] * j[0][8])          # largest B * N first: the short symbol-level layers fill the tail of the launch
+        for i in range(0, len(jobs), WGRAD_BATCH[taps]):
+            part = jobs[i:i + WGRAD_BATCH[taps]]
             arr = (_WgradJob * len(part))(*[_WgradJob(*fields) for fields, _ in part])
             if _lib.TIMER is not None:       # diagnostic pricing of the launch (profiling.price): descriptors by array address
                 WGRAD_BATCH_LOG[ctypes.addressof(arr)] = (arr, [fields for fields, _ in part])
