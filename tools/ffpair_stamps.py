@@ -19,7 +19,7 @@ def main():
     backward = len(sys.argv) > 1 and sys.argv[1] == 'bwd'
     ops.set_precision('bf16')
     batch = synthetic_batch(**CONFIGS['C2'])
-    lens = batch[9].to(dev).to(torch.int32)
+    lens = (batch[5] if os.environ.get('DX_STAMP_AXIS', 'frame') == 'symbol' else batch[9]).to(dev).to(torch.int32)
     if len(sys.argv) > 2:                                   # e.g. "fwd 8": only the first 8 utterances (few workgroups: an idle chip)
         lens = lens[:int(sys.argv[2])].contiguous()
     B, N, D, Fc = lens.numel(), int(lens.max()), 128, 1024
@@ -33,7 +33,8 @@ def main():
     h = torch.empty(B, N, Fc, dtype=torch.bfloat16, device=dev)
     aux = ops.conv_gemm(x, p1, b1, relu=True, lens=lens, halo=1, out_dtype=torch.bfloat16) if backward else None
     y = torch.zeros(B, N, D, device=dev)
-    nwg = B * ((N + 125) // 126)
+    tok = 126 if B * ((N + 125) // 126) >= 96 else 62      # the library's own choice of tile (dx_ffpair.hip: nj)
+    nwg = B * ((N + tok - 1) // tok)
     stamps = torch.zeros(nwg, 2, 16, dtype=torch.int64, device=dev)
     dll.dx_ff_pair_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
     P = lambda t: ctypes.c_void_p(None if t is None else t.data_ptr())
@@ -51,7 +52,7 @@ def main():
     dfilm = torch.zeros(B, 2 * D, device=dev)
     z1, mean1, rstd1, dy2 = rn(B, N, D), rn(B, N), rn(B, N).abs() + 0.5, rn(B, N, D) * valid
     F32 = ctypes.c_float
-    hmask = torch.zeros(B * ((N + 125) // 126), Fc // 128, 4, 2, 64, dtype=torch.int32, device=dev)
+    hmask = torch.zeros(B * ((N + 61) // 62), Fc // 128, 4, 2, 64, dtype=torch.int32, device=dev)
     if mode == 'block':                                  # real sign words from a forward run of the product library
         hmask = ops.ff_pair_ln(x, p1, p2, b1, b2, lens, res, ln_w, ln_b, film, want_mask=True)[-1]
     for _ in range(3):
