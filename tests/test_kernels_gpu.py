@@ -64,6 +64,32 @@ def test_conv_gemm_forward_dgrad_wgrad(ops, precision, tol, B, N, Cin, Cout, tap
         ops.set_precision('f32')
 
 
+def test_batched_weight_gradients_many_layers_in_one_launch(ops):
+    """More layers than one round of workgroups holds (dx_conv_wgrad_batched takes 32): 20 k = 1 layers of three shapes, one launch,
+    each against fp32 torch on the rounded operands."""
+    ops.set_precision('bf16')
+    try:
+        rt = ops.DEFAULT
+        rt.defer_wgrad = True
+        jobs = []
+        for i in range(20):
+            B, N, Cin, Cout = [(2, 100, 128, 128), (3, 77, 128, 384), (2, 130, 256, 128)][i % 3]
+            w = randn(Cout, Cin, seed=100 + i, scale=0.05)
+            pack = ops.PackedWeight(w)
+            x, dy = randn(B, N, Cin, seed=200 + i).to(torch.bfloat16), randn(B, N, Cout, seed=300 + i).to(torch.bfloat16)
+            gw, gb = torch.zeros_like(w), torch.zeros(Cout, device=DEV)
+            assert ops.conv_wgrad(dy, x, pack, None, -1, w_sink=gw, b_sink=gb, defer=True) == (None, None)
+            jobs.append((dy, x, gw, gb))
+        assert ops.flush_wgrads(rt) == 1
+        for dy, x, gw, gb in jobs:
+            ref = torch.einsum('bnc,bnd->cd', dy.float(), x.float())
+            assert rel_err(gw, ref) < 1e-4 and rel_err(gb, dy.float().sum((0, 1))) < 1e-4
+    finally:
+        rt.defer_wgrad = False
+        rt.wgrad_queue.clear()
+        ops.set_precision('f32')
+
+
 @pytest.mark.parametrize('precision', ['bf16', 'fp16'])
 @pytest.mark.parametrize('taps', [1, 3])
 def test_batched_weight_gradients_equal_single_launches(ops, precision, taps):
@@ -97,13 +123,13 @@ def test_batched_weight_gradients_equal_single_launches(ops, precision, taps):
         assert ops.flush_wgrads(rt) == 1 and not rt.wgrad_queue
         for (dy, x, pack, L, halo, ref_w, ref_b), (gw, gb) in zip(jobs, sinks):
             assert rel_err(gw, ref_w) < 2e-5 and rel_err(gb, ref_b) < 2e-5, (pack.cin, pack.cout)
-        # and against fp32 torch on the same 16-bit-rounded operands (first job)
-        dy, x, pack, L, halo, ref_w, ref_b = jobs[0]
-        xf = x.float().requires_grad_(False)
-        dyf = dy.float().clone()
-        wr = pack.weight.detach().clone().requires_grad_(True)
-        ref_conv(xf, wr, None, taps).backward(dyf)
-        assert rel_err(sinks[0][0], wr.grad) < 1e-4
+        # and against fp32 torch on the same 16-bit-rounded operands: every job (ragged ends inside a 64-token chunk, the halo row of
+        # the first / last chunk of an utterance, a partial output-channel tile, two input-channel tiles)
+        for (dy, x, pack, L, halo, ref_w, ref_b), (gw, gb) in zip(jobs, sinks):
+            wr = pack.weight.detach().clone().requires_grad_(True)
+            br = torch.zeros(pack.cout, device=DEV, requires_grad=True)
+            ref_conv(x.float(), wr, br, taps).backward(dy.float())
+            assert rel_err(gw, wr.grad) < 1e-4 and rel_err(gb, br.grad) < 1e-4, (pack.cin, pack.cout)
     finally:
         ops.DEFAULT.defer_wgrad = False
         ops.DEFAULT.wgrad_queue.clear()
