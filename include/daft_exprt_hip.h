@@ -245,6 +245,17 @@ int dx_loss_finalize(const float* ce, const float* spk_w_dev, float spk_w, const
                      const float* esum, float ecw, const float* psum, float pcw, float* terms, float* total, float grad_scale, void* stream);
 int dx_pitch_mse(const float* pp, int ldp, const float* gt, const int* lens, float* sums, int B, int T, void* stream);   /* ldp / ldd: element stride between consecutive frames of pp / dpp (the predictor's last conv writes 4-wide rows, channel 0 is the prediction) */
 int dx_pitch_grad(const float* pp, int ldp, const float* gt, const int* lens, const float* sums, float scale, float* dpp, int ldd, int B, int T, void* stream);
+/* The frozen pitch predictor of the pitch-consistency term, one launch per direction (layers/pitch_predictor.py:38-74 applied in loss.py:131-140):
+ * mel (B, M = 80, T) fp32 -> pp (B, T), and its input-gradient chain dpp (B, T) -> dmel (B, M, T) +=.  w0..w2: the 16-bit packs of the three
+ * 256-wide k = 3 convolutions written by dx_pack_weights (fwd takes the forward packs, bwd the backward packs); b*: biases; s* / t*: eval-mode
+ * BatchNorm folded to a scale / shift per channel; w3: row 0 of the last convolution's weight in checkpoint layout (256, 3) fp32, b3 its bias;
+ * masks: (B, T, 3, 8) uint32 written by fwd (ReLU sign bits: the network is frozen, so the backward needs no activations), read by bwd.
+ * Only tokens n < lens[b] are produced (the loss and the model mask the rest).  Every entry point with 16-bit packs also exists as <name>_f16. */
+int dx_pitch_chain_fwd(const float* mel, int B, int M, int T, const int* lens, const void* w0, const void* w1, const void* w2,
+                       const float* b0, const float* b1, const float* b2, const float* s0, const float* s1, const float* s2,
+                       const float* t0, const float* t1, const float* t2, const float* w3, float b3, float* pp, void* masks, void* stream);
+int dx_pitch_chain_bwd(const float* dpp, int B, int M, int T, const int* lens, const void* w0, const void* w1, const void* w2,
+                       const float* s0, const float* s1, const float* s2, const float* w3, const void* masks, float* dmel, void* stream);
 
 /* ---- on-device batch conditioning: dynamic_stats.py:131-195 ------------------------------------------------ */
 int dx_condition_prosody(const float* in, float* out, const long* speaker_ids, const float* table, const int* valid,

@@ -983,3 +983,77 @@ def test_ff_pair_fused_matches_two_launches_and_torch(ops, precision, B, N, lens
         assert torch.isfinite(dh.float()).all() and torch.isfinite(dx).all()
     finally:
         ops.set_precision('f32')
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+def test_fused_pitch_predictor_chain_matches_torch_and_the_layer_launches(ops, precision):
+    """csrc/dx_pitch.hip (layers/pitch_predictor.py:38-74 in one launch per direction) against fp32 torch on the folded weights, forward and
+    input gradient, at utterance lengths around the 122-token tile (1, a tile, a tile + 1, two tiles - 1, the tensor's end).  The bar is the
+    layer-by-layer launches' own distance from torch on the same inputs (16-bit activations flip the ReLU of near-zero pre-activations: ~6 % of
+    the gradient norm in bf16 on this random network, for both forms); the ReLU sign bits handed to the backward are checked exactly wherever
+    torch's pre-activation is clearly away from zero."""
+    from ubisoft_laforge_daft_exprt_amd import loss as L
+    ops.set_precision(precision)
+    try:
+        g = torch.Generator().manual_seed(7)
+        state = {}
+        for k, shape in L.pitch_predictor_shapes().items():
+            if k.endswith('num_batches_tracked'):
+                state[k] = torch.tensor(10)
+            elif k.endswith('running_var') or k.endswith('weight_g'):
+                state[k] = torch.rand(shape, generator=g) + 0.5
+            else:
+                state[k] = torch.randn(shape, generator=g) * (0.3 if 'weight_v' in k else 0.2)
+        layers = L.fold_pitch_predictor(state, DEV, ops.DEFAULT)
+        lens_h = [1, 122, 123, 243, 300, 57]
+        B, M, T = len(lens_h), 80, 300
+        lens = lens_tensor(lens_h)
+        valid = (torch.arange(T, device=DEV)[None, :] < lens[:, None])
+        vm = valid[:, None, :]
+        mel = (randn(B, M, T, seed=3) * vm).contiguous()
+        dpp = (randn(B, T, seed=5) * valid).contiguous()
+        assert ops.pitch_chain_applies(layers, mel, precision)
+        pp, masks = ops.pitch_chain_fwd(mel, layers, lens, precision)
+        dmel = torch.zeros_like(mel)
+        ops.pitch_chain_bwd(dpp, masks, layers, lens, precision, dmel)
+        # torch, fp32, on the same folded weights
+        melr = mel.clone().requires_grad_(True)
+        x, pre = melr, []
+        for l in layers[:3]:
+            v = F.conv1d(x, l['w'], l['b'], padding=1)
+            pre.append(v.detach())
+            x = v.relu() * l['scale'][None, :, None] + l['shift'][None, :, None]
+        pp_ref = F.conv1d(x, layers[3]['w'][:1], layers[3]['b'][:1], padding=1)[:, 0]
+        (pp_ref * dpp).sum().backward()
+        # the layer-by-layer launches (loss.py's other branch)
+        hd = ops.hidden_dtype(precision)
+        xl, acts = ops.transpose(mel), []
+        for i, layer in enumerate(layers[:-1]):
+            r = ops.conv_gemm(xl, layer['pack'], layer['b'], relu=True, lens=lens, halo=3 - i, prec=precision, out_dtype=hd)
+            acts.append(r)
+            xl = ops.channel_affine(r, layer['scale'], layer['shift'], prec=precision)
+        pp_l = ops.conv_gemm(xl, layers[-1]['pack'], layers[-1]['b'], lens=lens, halo=0, prec=precision)[..., 0]
+        gl = torch.zeros(B, T, 4, device=DEV)
+        gl[..., 0] = dpp
+        for k in range(3, 0, -1):
+            prev = layers[k - 1]
+            gl = ops.conv_gemm(gl, layers[k]['pack'], None, transpose=True, post_scale=prev['scale'], post_shift=prev['zeros'], relu_aux=acts[k - 1],
+                               lens=lens, halo=4 - k, prec=precision, out_dtype=hd)
+        dmel_l = ops.transpose(ops.conv_gemm(gl, layers[0]['pack'], None, transpose=True, lens=lens, halo=0, prec=precision))
+
+        def dist(a, b, m):
+            return float(((a - b) * m).norm() / (b * m).norm())
+        e_pp, e_pp_l = dist(pp, pp_ref.detach(), valid), dist(pp_l, pp_ref.detach(), valid)
+        e_g, e_g_l = dist(dmel, melr.grad, vm), dist(dmel_l, melr.grad, vm)
+        bar_pp, bar_g = {'bf16': (3e-2, 9e-2), 'fp16': (4e-3, 4e-2)}[precision]      # (measured: bf16 2.1e-2 / 6.3e-2, fp16 2.5e-2 for the gradient; the layer launches 2.2e-2 / 6.5e-2 / 2.6e-2)
+        assert e_pp < bar_pp and e_pp < 1.25 * e_pp_l + 1e-3, (e_pp, e_pp_l)
+        assert e_g < bar_g and e_g < 1.25 * e_g_l + 1e-3, (e_g, e_g_l)
+        assert float((dmel * ~vm).abs().max()) == 0.0                                     # nothing written beyond the lengths
+        for l in range(3):
+            bits = masks[:, :, l].contiguous()                                            # (B, T, 8) int32
+            sign = ((bits[:, :, :, None] >> torch.arange(32, device=DEV)) & 1).reshape(B, T, 256).bool()
+            v0 = pre[l].transpose(1, 2)                                                   # (B, T, 256)
+            clear = (v0.abs() > 0.05) & valid[:, :, None]
+            assert bool(((sign == (v0 > 0)) | ~clear).all()), l
+    finally:
+        ops.set_precision('f32')

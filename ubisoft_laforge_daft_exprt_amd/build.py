@@ -9,8 +9,8 @@ from concurrent.futures import ThreadPoolExecutor
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(PKG, 'libdaft_exprt_hip.so')
-SOURCES = ['dx_runtime.hip', 'dx_gemm.hip', 'dx_ffpair.hip', 'dx_attention.hip', 'dx_rows.hip', 'dx_upsample.hip', 'dx_loss.hip', 'dx_optim.hip']
-F16_SOURCES = ['dx_gemm.hip', 'dx_ffpair.hip', 'dx_attention.hip', 'dx_rows.hip']    # compiled a second time with -DDX_F16 (fp16 operand mode)
+SOURCES = ['dx_runtime.hip', 'dx_gemm.hip', 'dx_ffpair.hip', 'dx_attention.hip', 'dx_rows.hip', 'dx_upsample.hip', 'dx_loss.hip', 'dx_optim.hip', 'dx_pitch.hip']
+F16_SOURCES = ['dx_gemm.hip', 'dx_ffpair.hip', 'dx_attention.hip', 'dx_rows.hip', 'dx_pitch.hip']    # compiled a second time with -DDX_F16 (fp16 operand mode)
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wno-unused-value', '-Wno-unused-result'] + os.environ.get('DX_EXTRA_HIPCC_FLAGS', '').split()
 
 

@@ -17,6 +17,7 @@ from .functional import Lengths
 
 
 _PITCH_16BIT = os.environ.get('DX_PITCH_16BIT', '1') != '0'
+_PITCH_FUSED = os.environ.get('DX_PITCH_FUSED', '1') != '0'      # 0: the layer-by-layer launches also in the 16-bit modes (A/B timing, tests)
 
 
 def pitch_predictor_shapes(n_mel_channels=80, hidden_dim=256, kernel_size=3):
@@ -66,6 +67,7 @@ def fold_pitch_predictor(state_dict, device, rt=None):
     wpad[:1] = last['w']
     bpad = torch.zeros(4, device=device)
     bpad[:1] = last['b']
+    last['b3'] = float(last['b'][0])        # (host copy of the one bias the fused chain takes by value; read once here, at load time)
     last['w'], last['b'] = wpad, bpad
     for layer in layers:
         layer['pack'] = ops.PackedWeight(layer['w'], rt)
@@ -99,29 +101,37 @@ class _LossFn(torch.autograd.Function):
                             gs * cfg['ecw'] if des is not None else 0.0, e_per_total=True) if need_grad else None
         psum = None
         if pitch_layers is not None and frames_pitch is not None and cfg['pcw'] > 0:
-            # frozen predictor on the predicted mel, channels-last; gradient flows through it to the mel only
-            x = ops.transpose(mel_pred)                                          # (B, T, M)
             prec = pitch_layers[0]['pack'].rt.precision                          # one value for the whole chain
-            acts = []
-            depth = len(pitch_layers) - 1                                       # stacked k=3 convs: halos 3, 2, 1, 0
-            hd = ops.hidden_dtype(prec) if _PITCH_16BIT else torch.float32     # 16-bit modes: the 256-wide activations of the frozen predictor
-            for i, layer in enumerate(pitch_layers[:-1]):                      # (only ever GEMM operands / ReLU masks) are stored in 16 bits
-                r = ops.conv_gemm(x, layer['pack'], layer['b'], relu=True, lens=lens.i32, halo=depth - i, prec=prec, out_dtype=hd)
-                acts.append(r)
-                x = ops.channel_affine(r, layer['scale'], layer['shift'], prec=prec)
-            last = pitch_layers[-1]
-            pp = ops.conv_gemm(x, last['pack'], last['b'], lens=lens.i32, halo=0, prec=prec)      # (B, T, 4): channel 0 is the prediction
             frames_pitch = frames_pitch.contiguous()
-            psum = ops.pitch_mse(pp, frames_pitch, lens.i32, arena=arena)                          # (read and written in place: no slice copies)
-            if need_grad:
-                g = ops.pitch_grad(pp, frames_pitch, lens.i32, psum, gs * cfg['pcw'], out=ops._zeros(arena, B, T, 4, device=dev))
-                # each input-gradient GEMM applies the previous layer's BatchNorm scale and ReLU mask in its epilogue
-                for k in range(len(pitch_layers) - 1, 0, -1):
-                    prev = pitch_layers[k - 1]
-                    g = ops.conv_gemm(g, pitch_layers[k]['pack'], None, transpose=True, post_scale=prev['scale'], post_shift=prev['zeros'],
-                                      relu_aux=acts[k - 1], lens=lens.i32, halo=depth - k + 1, prec=prec, out_dtype=hd)
-                d = ops.conv_gemm(g, pitch_layers[0]['pack'], None, transpose=True, lens=lens.i32, halo=0, prec=prec)
-                dmel = ops.transpose(d, add_to=dmel)                                   # dmel is this function's own fresh tensor
+            if _PITCH_FUSED and ops.pitch_chain_applies(pitch_layers, mel_pred, prec):
+                # one launch each way (csrc/dx_pitch.hip): activations stay in LDS, the backward gets ReLU sign bits instead of activations
+                pp, masks = ops.pitch_chain_fwd(mel_pred, pitch_layers, lens.i32, prec, arena=arena)
+                psum = ops.pitch_mse(pp, frames_pitch, lens.i32, arena=arena)
+                if need_grad:
+                    g = ops.pitch_grad(pp, frames_pitch, lens.i32, psum, gs * cfg['pcw'], out=ops._zeros(arena, B, T, device=dev))
+                    ops.pitch_chain_bwd(g, masks, pitch_layers, lens.i32, prec, dmel)              # dmel is this function's own fresh tensor
+            else:
+                # layer by layer (the exact-fp32 mode, other architectures): channels-last; gradient flows through it to the mel only
+                x = ops.transpose(mel_pred)                                          # (B, T, M)
+                acts = []
+                depth = len(pitch_layers) - 1                                       # stacked k=3 convs: halos 3, 2, 1, 0
+                hd = ops.hidden_dtype(prec) if _PITCH_16BIT else torch.float32     # 16-bit modes: the 256-wide activations of the frozen predictor
+                for i, layer in enumerate(pitch_layers[:-1]):                      # (only ever GEMM operands / ReLU masks) are stored in 16 bits
+                    r = ops.conv_gemm(x, layer['pack'], layer['b'], relu=True, lens=lens.i32, halo=depth - i, prec=prec, out_dtype=hd)
+                    acts.append(r)
+                    x = ops.channel_affine(r, layer['scale'], layer['shift'], prec=prec)
+                last = pitch_layers[-1]
+                pp = ops.conv_gemm(x, last['pack'], last['b'], lens=lens.i32, halo=0, prec=prec)      # (B, T, 4): channel 0 is the prediction
+                psum = ops.pitch_mse(pp, frames_pitch, lens.i32, arena=arena)                          # (read and written in place: no slice copies)
+                if need_grad:
+                    g = ops.pitch_grad(pp, frames_pitch, lens.i32, psum, gs * cfg['pcw'], out=ops._zeros(arena, B, T, 4, device=dev))
+                    # each input-gradient GEMM applies the previous layer's BatchNorm scale and ReLU mask in its epilogue
+                    for k in range(len(pitch_layers) - 1, 0, -1):
+                        prev = pitch_layers[k - 1]
+                        g = ops.conv_gemm(g, pitch_layers[k]['pack'], None, transpose=True, post_scale=prev['scale'], post_shift=prev['zeros'],
+                                          relu_aux=acts[k - 1], lens=lens.i32, halo=depth - k + 1, prec=prec, out_dtype=hd)
+                    d = ops.conv_gemm(g, pitch_layers[0]['pack'], None, transpose=True, lens=lens.i32, halo=0, prec=prec)
+                    dmel = ops.transpose(d, add_to=dmel)                                   # dmel is this function's own fresh tensor
         # the seven terms, the total and the two small gradients: one launch (was ~30 one-element ATen launches)
         terms, total, d_spk, d_pm = ops.loss_finalize(ce, dlogits, cfg['spk_weight'], pm, cfg['pmw'], sums, lens.i32, M, cfg['msw'],
                                                       esum, cfg['ecw'], psum, cfg['pcw'], grad_scale=gs)

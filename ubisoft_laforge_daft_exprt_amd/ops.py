@@ -838,6 +838,41 @@ def pitch_grad(pp, gt, lens, sums, scale, out=None):
     return dpp
 
 
+def pitch_chain_applies(layers, mel, prec) -> bool:
+    """The fused frozen-predictor launches (csrc/dx_pitch.hip) cover the reference architecture in the 16-bit modes: three 256-wide k = 3
+    convolutions with folded BatchNorm and a k = 3 convolution to one channel, n_mel <= 96."""
+    if not _half(prec) or len(layers) != 4 or mel.dim() != 3 or mel.shape[1] > 96 or mel.shape[1] % 4 or mel.shape[0] > 1000:
+        return False
+    shapes = [tuple(l['pack'].weight.shape) for l in layers]
+    M = mel.shape[1]
+    return (shapes[0] == (256, M, 3) and shapes[1] == (256, 256, 3) and shapes[2] == (256, 256, 3) and shapes[3][1:] == (256, 3)
+            and all(l['scale'] is not None for l in layers[:3]))
+
+
+def pitch_chain_fwd(mel, layers, lens, prec, arena=None):
+    """(pp (B, T), masks) = the frozen pitch predictor on mel (B, n_mel, T) fp32 in one launch; ``masks`` feeds pitch_chain_bwd."""
+    B, M, T = mel.shape
+    pp = _zeros(arena, B, T, device=mel.device)          # tokens >= len are never written (and never read unmasked)
+    masks = torch.empty(B, T, 3, 8, dtype=torch.int32, device=mel.device)
+    img = [l['pack'].image(prec) for l in layers[:3]]
+    _fn('dx_pitch_chain_fwd', prec)(_p(mel), B, M, T, _p(lens), _p(img[0].fwd), _p(img[1].fwd), _p(img[2].fwd),
+                                    _p(layers[0]['b']), _p(layers[1]['b']), _p(layers[2]['b']),
+                                    _p(layers[0]['scale']), _p(layers[1]['scale']), _p(layers[2]['scale']),
+                                    _p(layers[0]['shift']), _p(layers[1]['shift']), _p(layers[2]['shift']),
+                                    _p(layers[3]['w']), float(layers[3]['b3']), _p(pp), _p(masks), _stream())
+    return pp, masks
+
+
+def pitch_chain_bwd(dpp, masks, layers, lens, prec, dmel):
+    """dmel (B, n_mel, T) += the gradient of the frozen predictor's output with respect to its input mel, from dpp (B, T)."""
+    B, M, T = dmel.shape
+    img = [l['pack'].image(prec) for l in layers[:3]]
+    _fn('dx_pitch_chain_bwd', prec)(_p(dpp), B, M, T, _p(lens), _p(img[0].bwd), _p(img[1].bwd), _p(img[2].bwd),
+                                    _p(layers[0]['scale']), _p(layers[1]['scale']), _p(layers[2]['scale']),
+                                    _p(layers[3]['w']), _p(masks), _p(dmel), _stream())
+    return dmel
+
+
 def relu_bwd(dy, y):
     out = torch.empty_like(dy)
     lib().dx_relu_bwd(_p(dy), _p(y), _p(out), dy.numel(), _stream())
