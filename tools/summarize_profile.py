@@ -32,6 +32,7 @@ LABELS = [
     ('transpose', r'transpose_kernel'), ('mask_rows', r'mask_rows_kernel'), ('mean_pool', r'mean_pool_kernel'),
     ('mean_pool_bwd', r'mean_pool_bwd_kernel'), ('channel_affine', r'channel_affine_kernel'), ('relu_bwd', r'relu_bwd_kernel'),
     ('colsum', r'colsum_kernel'), ('pack_weights_batched', r'pack_weights_batched|pack_weights_flat'),
+    ('pitch_chain<fwd>', r'pitch_fwd_kernel'), ('pitch_chain<bwd>', r'pitch_bwd_kernel'),
 ]
 
 

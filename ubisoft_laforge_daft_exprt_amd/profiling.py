@@ -110,6 +110,11 @@ def price(name, a, geom: Geometry):
             return 'attn_fwd', 'mfma', 4.0 * pairs * D, rows * (3 * D * qb + D * 4 + H * 4)
         gb = 2 if a['dqkv_bf16'] else 4                      # dQ kernel: S, dP, dQ; dK/dV kernel: S, dP, dV, dK: 7 products
         return 'attn_bwd (dq + dkv)', 'mfma', 14.0 * pairs * D, rows * (2 * 3 * D * qb + 2 * D * 4 + 3 * D * gb + 2 * H * 4)
+    if name in ('dx_pitch_chain_fwd', 'dx_pitch_chain_bwd'):      # the frozen predictor: 3 taps x (M x 256 + 2 x 256 x 256) MACs per token + the one-channel layer
+        rows = geom.rows(a['B'], a['T'], True)
+        flops = 2.0 * 3 * (a['M'] * 256 + 2 * 256 * 256 + 256) * rows
+        byt = rows * (a['M'] * 4 + 4 + 96 + (a['M'] * 8 if name.endswith('bwd') else 0))       # mel / pp (dpp) / sign bits; backward: dmel read + written
+        return ('pitch_chain<fwd>' if name.endswith('fwd') else 'pitch_chain<bwd>'), 'mfma', flops, byt
     if name == 'dx_ln_fwd':
         rows = geom.rows(a['B'], a['N'], has('lens'))
         C, ab = a['C'], (2 if a['io_bf16'] else 4)
