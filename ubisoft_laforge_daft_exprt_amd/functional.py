@@ -97,8 +97,10 @@ class LinearFn(torch.autograd.Function):
         if ctx.relu:
             dy = ops.relu_bwd(dy, y)
         # gradient sink: the weight-gradient launch adds straight into the bucket views (no zero fill, no AccumulateGrad add per parameter)
+        # (utterance-level linears - classifier, FiLM predictors, projections - are 48-row products of ~9 us each as launches of their own: queued,
+        # they ride in ONE batched launch with the other k = 1 layers of their operand kind at the end of the backward phase)
         dw, db = ops.conv_wgrad(dy, x2, ctx.pack, arena=ctx.pack.rt.arena, w_sink=_sink(ctx.params[0], ctx.sink), b_sink=_sink(ctx.params[1], ctx.sink),
-                                prec=ctx.prec)
+                                prec=ctx.prec, defer=ctx.lens is None)
         dx = None
         if ctx.need_dx:
             dx = ops.conv_gemm(dy, ctx.pack, None, transpose=True, out_scale=ctx.grad_scale, prec=ctx.prec).view(ctx.xshape)
