@@ -150,14 +150,12 @@ __global__ __launch_bounds__(512) void pitch_fwd_kernel(const PitchArgs a) {
     b = __builtin_amdgcn_readfirstlane(b); n0 = __builtin_amdgcn_readfirstlane(n0);
     __syncthreads();                                   // the previous tile's readers of the images / scratch are done
     // ---- window of the mel -> image A (channels 0..79 real, 80..95 zero), sign-bit staging area zeroed -----------------------------------
-    for (int u = tid; u < a.M * PC_IR; u += 512) {
+    for (int u = tid; u < 96 * PC_IR; u += 512) {      // the first layer walks 96 input channels (three K steps): channels M..95 are zeros
       const int c = u / PC_IR, p = u - c * PC_IR;
       const int n = n0 - 4 + p;
-      const float v = (n >= 0 && n < a.T) ? a.mel[((size_t)b * a.M + c) * a.T + n] : 0.f;
+      const float v = (c < a.M && n >= 0 && n < a.T) ? a.mel[((size_t)b * a.M + c) * a.T + n] : 0.f;
       *reinterpret_cast<dx_h16*>(imgA + (c >> 6) * PC_CHUNK + pc_off(p, (c & 63) >> 3) + (c & 7) * 2) = (dx_h16)v;
     }
-    for (int u = tid; u < PC_IR * 2; u += 512)         // channels 80..95: slots 2, 3 of chunk 1
-      *reinterpret_cast<f32x4*>(imgA + PC_CHUNK + pc_off(u >> 1, 2 + (u & 1))) = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int u = tid; u < PC_MASK / 4; u += 512) mask_s[u] = 0u;
     __syncthreads();
 
@@ -347,7 +345,7 @@ int dx_pitch_chain_fwd(const float* mel, int B, int M, int T, const int* lens, c
                        const float* b0, const float* b1, const float* b2, const float* s0, const float* s1, const float* s2,
                        const float* t0, const float* t1, const float* t2, const float* w3, float b3, float* pp, void* masks, void* stream) {
   DX_REQUIRE(mel && lens && w0 && w1 && w2 && b0 && b1 && b2 && s0 && s1 && s2 && t0 && t1 && t2 && w3 && pp && masks, "dx_pitch_chain_fwd: null pointer");
-  DX_REQUIRE(B > 0 && B <= PC_MAX_B && T > 0 && M > 0 && M <= 96 && (M % 4) == 0, "dx_pitch_chain_fwd: B <= %d, n_mel <= 96 and a multiple of 4 (B=%d M=%d)", PC_MAX_B, B, M);
+  DX_REQUIRE(B > 0 && B <= PC_MAX_B && T > 0 && M > 64 && M <= 96, "dx_pitch_chain_fwd: B <= %d and 64 < n_mel <= 96 (the first layer's pack must be 128 wide: B=%d M=%d)", PC_MAX_B, B, M);
   PitchArgs a{};
   a.mel = mel; a.B = B; a.M = M; a.T = T; a.lens = lens;
   a.w0 = (const dx_h16*)w0; a.w1 = (const dx_h16*)w1; a.w2 = (const dx_h16*)w2;
@@ -370,7 +368,7 @@ int dx_pitch_chain_fwd(const float* mel, int B, int M, int T, const int* lens, c
 int dx_pitch_chain_bwd(const float* dpp, int B, int M, int T, const int* lens, const void* w0, const void* w1, const void* w2,
                        const float* s0, const float* s1, const float* s2, const float* w3, const void* masks, float* dmel, void* stream) {
   DX_REQUIRE(dpp && lens && w0 && w1 && w2 && s0 && s1 && s2 && w3 && masks && dmel, "dx_pitch_chain_bwd: null pointer");
-  DX_REQUIRE(B > 0 && B <= PC_MAX_B && T > 0 && M > 0 && M <= 96 && (M % 4) == 0, "dx_pitch_chain_bwd: B <= %d, n_mel <= 96 and a multiple of 4 (B=%d M=%d)", PC_MAX_B, B, M);
+  DX_REQUIRE(B > 0 && B <= PC_MAX_B && T > 0 && M > 64 && M <= 96, "dx_pitch_chain_bwd: B <= %d and 64 < n_mel <= 96 (B=%d M=%d)", PC_MAX_B, B, M);
   PitchArgs a{};
   a.dpp = dpp; a.B = B; a.M = M; a.T = T; a.lens = lens; a.dmel = dmel;
   a.w0 = (const dx_h16*)w0; a.w1 = (const dx_h16*)w1; a.w2 = (const dx_h16*)w2;

@@ -840,8 +840,8 @@ def pitch_grad(pp, gt, lens, sums, scale, out=None):
 
 def pitch_chain_applies(layers, mel, prec) -> bool:
     """The fused frozen-predictor launches (csrc/dx_pitch.hip) cover the reference architecture in the 16-bit modes: three 256-wide k = 3
-    convolutions with folded BatchNorm and a k = 3 convolution to one channel, n_mel <= 96."""
-    if not _half(prec) or len(layers) != 4 or mel.dim() != 3 or mel.shape[1] > 96 or mel.shape[1] % 4 or mel.shape[0] > 1000:
+    convolutions with folded BatchNorm and a k = 3 convolution to one channel, 64 < n_mel <= 96 (the reference: 80)."""
+    if not _half(prec) or len(layers) != 4 or mel.dim() != 3 or not (64 < mel.shape[1] <= 96) or mel.shape[0] > 1000:
         return False
     shapes = [tuple(l['pack'].weight.shape) for l in layers]
     M = mel.shape[1]
