@@ -156,6 +156,14 @@ int dx_length_order(const int* lens, int* order, int B, void* stream);
 int dx_attention_fwd(const void* qkv, int ld, const int* lens, void* ctx, int ldc, float* lse,
                      int B, int N, int H, int D, uint64_t seed, const uint64_t* seed_offset, float p_drop, int bf16, int qkv_bf16, int ctx_bf16,
                      const int* order, void* stream);
+/* dx_attention_fwd (16-bit q/k/v and context, 2 heads x 64) + dx_proj_ln_fwd on its result in ONE launch, bit-identical outputs: the
+ * attention, out-projection, dropout, residual and first LayerNorm of an FFT block (model.py:165-191, forward).  Arguments as in the two
+ * entry points (halo 0).  Every entry point with 16-bit operands also exists as <name>_f16. */
+int dx_attention_proj_ln_fwd(const void* qkv, int ld, const int* lens, void* ctx, int ldc, float* lse, int B, int N, int H, int D,
+                             uint64_t seed, const uint64_t* seed_offset, float p_drop,
+                             const void* Wpack, const float* proj_bias, float* z, const float* res, const float* w, const float* bias,
+                             const float* film, int ld_film, float* y, float* mean, float* rstd, uint64_t seed_pre, float p_pre,
+                             void* y_bf16_copy, void* stream);
 int dx_attention_bwd(const void* qkv, int ld, const void* ctx, const void* dctx, int ldc, const float* lse, float* delta,
                      const int* lens, void* dqkv, int ldg, int B, int N, int H, int D, uint64_t seed, const uint64_t* seed_offset, float p_drop, int bf16,
                      int qkv_bf16, int dqkv_bf16, int ctx_bf16, const int* order, void* stream);

@@ -1057,3 +1057,31 @@ def test_fused_pitch_predictor_chain_matches_torch_and_the_layer_launches(ops, p
             assert bool(((sign == (v0 > 0)) | ~clear).all()), l
     finally:
         ops.set_precision('f32')
+
+
+@pytest.mark.parametrize('precision', ['bf16', 'fp16'])
+@pytest.mark.parametrize('lens_h,N,p', [([257, 64, 1, 200], 257, 0.1), ([150, 149, 7, 128, 65, 33, 150, 2, 90], 150, 0.0), ([83, 120], 120, 0.1)])
+def test_attention_projection_layernorm_in_one_launch_equals_the_two_launches_bitwise(ops, precision, lens_h, N, p):
+    """dx_attention_proj_ln_fwd == dx_attention_fwd + dx_proj_ln_fwd, bit for bit (context, lse, z, y, its 16-bit copy, mean, rstd), with
+    dropout in both places, ragged lengths (a 1-token utterance, lengths at and around the 64-query tile), padding tiles, 9 utterances
+    (the utterance -> XCD numbering pads to a multiple of 8)."""
+    ops.set_precision(precision)
+    try:
+        h16 = {'bf16': torch.bfloat16, 'fp16': torch.float16}[precision]
+        B = len(lens_h)
+        lens = lens_tensor(lens_h)
+        qkv = randn(B, N, 384, seed=1).to(h16)
+        res = randn(B, N, 128, seed=2)
+        wout, bout = randn(128, 128, seed=3, scale=0.09), randn(128, seed=4, scale=0.1)
+        ln_w, ln_b = 1 + randn(128, seed=5, scale=0.1), randn(128, seed=6, scale=0.1)
+        pack = ops.PackedWeight(wout)
+        so = torch.tensor([5], dtype=torch.int64, device=DEV)
+        ctx0, lse0 = ops.attention_fwd(qkv, lens, 2, 11, p, ctx_dtype=h16, seed_offset=so)
+        z0, y0, m0, r0, yh0 = ops.proj_ln_fwd(ctx0, pack, bout, res, ln_w, ln_b, None, lens, seed_pre=12, p_pre=p, shadow=True, seed_offset=so)
+        assert ops.attn_proj_ln_applies(qkv, 2, pack, precision)
+        ctx1, lse1, z1, y1, m1, r1, yh1 = ops.attn_proj_ln_fwd(qkv, lens, 2, 11, p, pack, bout, res, ln_w, ln_b, None, seed_pre=12, p_pre=p, shadow=True,
+                                                               seed_offset=so)
+        for name, a, b in (('ctx', ctx0, ctx1), ('lse', lse0, lse1), ('z', z0, z1), ('y', y0, y1), ('y16', yh0, yh1), ('mean', m0, m1), ('rstd', r0, r1)):
+            assert torch.equal(a, b), name
+    finally:
+        ops.set_precision('f32')

@@ -22,7 +22,7 @@ LABELS = [
     ('wgrad_bf16_kernel<3,wide>', r'wgrad_bf16_kernel<3, (true|false), (true|false), 4>'), ('wgrad_bf16_kernel<1,wide>', r'wgrad_bf16_kernel<1, (true|false), (true|false), 4>'),
     ('wgrad_bf16_kernel<3>', r'wgrad_bf16_kernel<3,'), ('wgrad_bf16_kernel<1>', r'wgrad_bf16_kernel<1,'),
     ('wgrad_kernel<3>', r'wgrad_kernel<3>'), ('wgrad_kernel<1>', r'wgrad_kernel<1>'),
-    ('attn_fwd', r'attn_fwd'), ('attn_bwd (dq + dkv)', r'attn_bwd_(dq|dkv)|attn_delta'),
+    ('attn_fwd+proj_ln', r'attn_proj_ln_fwd'), ('attn_fwd', r'attn_fwd'), ('attn_bwd (dq + dkv)', r'attn_bwd_(dq|dkv)|attn_delta'),
     ('ln_fwd_kernel<128>', r'ln_fwd_kernel<128'), ('ln_fwd_kernel<1024>', r'ln_fwd_kernel<1024|ln_fwd_kernelILi1024E'),
     ('ln_bwd_kernel<128>', r'ln_bwd_kernel<128'), ('ln_bwd_kernel<1024>', r'ln_bwd_kernel<1024|ln_bwd_kernelILi1024E'), ('loss_finalize', r'loss_finalize_kernel'), ('proj_ln_fwd', r'proj_ln_fwd_kernel'),
     ('upsample_fwd', r'upsample_fwd_kernel'), ('upsample_bwd (dsigma + dxs)', r'upsample_(bwd|dxs)_kernel'),

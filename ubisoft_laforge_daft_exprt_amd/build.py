@@ -24,7 +24,7 @@ def _stale(target, deps):
 def _compile(job):
     src, f16 = job
     obj = os.path.join(CSRC, os.path.splitext(src)[0] + ('_f16.o' if f16 else '.o'))
-    deps = [os.path.join(CSRC, src), os.path.join(CSRC, 'dx_common.h'), os.path.join(CSRC, 'dx_f16_names.h')]
+    deps = [os.path.join(CSRC, src), os.path.join(CSRC, 'dx_common.h'), os.path.join(CSRC, 'dx_f16_names.h'), os.path.join(CSRC, 'dx_rowvec.h')]
     if _stale(obj, deps):
         subprocess.run(['hipcc', *FLAGS, *(['-DDX_F16'] if f16 else []), '-c', os.path.join(CSRC, src), '-o', obj], check=True)
     return obj

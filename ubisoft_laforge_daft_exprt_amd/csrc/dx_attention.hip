@@ -415,6 +415,8 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ int sw_off(int row, int slot) { return row * 128 + ((slot ^ (row & 7)) << 4); }
 
+#include "dx_rowvec.h"
+
 // stage rows [r0, r0+64) x 64 fp32 columns (from col0) as bf16 into the swizzled image; rows >= N are zero
 __device__ __forceinline__ void stage_tile_bf16(unsigned char* dst, const float* base, int ld, int col0, int r0, int N, int tid, float scale) {
 #pragma unroll
@@ -652,6 +654,263 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const AttnArgs a_
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) store4(out + dt * 16 + g * 4, o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
     if (g == 0) a.lse[((size_t)b * a.H + h) * a.N + qrow] = valid ? m_run + __log2f(l_run) : 0.f;   // base 2 (see QSCALE2)
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention forward of BOTH heads + out-projection + dropout + residual + LayerNorm (+ FiLM + mask) of an FFT block in ONE launch
+// (16-bit q/k/v and context, 2 heads x 64, model width 128).  As two launches (attn_fwd_bf16_kernel, then proj_ln_fwd_kernel of dx_rows.hip)
+// the second one is a one-round, latency-bound shell of 17-19 us per frame-level block that re-reads the context; here a 512-thread
+// workgroup owns a 64-query tile of one utterance: waves 0-3 run head 0 and waves 4-7 head 1 exactly as attn_fwd_bf16_kernel does (own
+// K / V images, same arithmetic, same dropout draws), the normalised context goes to HBM (the backward needs it) AND into an LDS image,
+// the 128 x 128 out-projection is 16 MFMAs per wave from that image, and the row pass of proj_ln_fwd_kernel runs on the result while other
+// workgroups are still in their key loops (utterances differ in length, so the HBM-bound row pass hides under their VALU-bound loops).
+// Results are bit-identical to the two launches (same operands, same K order, same row arithmetic): the test compares bitwise.
+// ------------------------------------------------------------------------------------------------
+constexpr float APL_LN_EPS = 1e-5f;          // (= LN_EPS of dx_rows.hip)
+struct AttnProjLnArgs {
+  AttnArgs at;
+  const dx_h16* Wp; const float* proj_bias;                       // out-projection: forward pack of the (128, 128) weight, bias
+  float* z; const float* res; const float* w; const float* bias;  // as LnArgs of dx_rows.hip (C = 128, fp32 rows)
+  const float* film; int ld_film;
+  float* y; dx_h16* y_h; float* mean; float* rstd;
+  uint64_t seed_pre; uint32_t thresh_pre; float inv_keep_pre;
+};
+
+__global__ __launch_bounds__(512, 4) void attn_proj_ln_fwd_kernel(const AttnProjLnArgs p_) {
+  typedef dx_h16 QT;
+  typedef dx_h16 CT;
+  constexpr int C = 128;
+  AttnArgs a = p_.at;
+  uint64_t seed_pre = p_.seed_pre;
+  if (a.seed_offset) { const uint64_t o = *a.seed_offset; a.seed += o; seed_pre += o; }
+  // LDS: K and V images of both heads (32 KB; after the key loop: the fp32 projection tile), the 16-bit context image (16 KB)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * 64 * 128 + 64 * 256];
+  const int tid512 = threadIdx.x, lane = tid512 & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid512 >> 6);
+  const int h = wave >> 2, wq = wave & 3;
+  const int tid = tid512 & 255;                         // the staging macros walk 256 threads per (head) image
+  unsigned char* const Ks = smem + h * (64 * 128);
+  unsigned char* const Vs = smem + 2 * 64 * 128 + h * (64 * 128);
+  unsigned char* const Cs = smem + 4 * 64 * 128;        // [64 rows][256 B]: 16 slots of 8 channels, slot ^ (row & 15)
+  float* const tile = reinterpret_cast<float*>(smem);   // [64][128] fp32, 4-float slots ^ (row & 15) (as proj_ln_fwd_kernel)
+  const int r = lane & 15, g = lane >> 4;
+  // workgroup -> (utterance, query tile): the tiles of an utterance run on ONE XCD (K / V fetched once), utterances go round the XCDs
+  const int ntx = (a.N + 63) / 64;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int b = (j / ntx) * 8 + xcd, q0 = (j - (j / ntx) * ntx) * 64;
+  if (b >= a.B) return;
+  const int len = a.lens[b];
+  const QT* base = reinterpret_cast<const QT*>(a.qkv) + (size_t)b * a.N * a.ld;
+  const int qrow = q0 + wq * 16 + r;
+  CT* out = reinterpret_cast<CT*>(a.ctx) + ((size_t)b * a.N + qrow) * a.ldc + h * HD;
+  constexpr int E = RowVec<C>::E, LPR = RowVec<C>::LPR;
+  const int l = lane % LPR, sub = lane / LPR;
+  if (q0 >= len) {                                      // a padding tile: what the two launches leave there
+    if (qrow < a.N) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) store4(out + dt * 16 + g * 4, 0.f, 0.f, 0.f, 0.f);
+      if (g == 0) a.lse[((size_t)b * a.H + h) * a.N + qrow] = 0.f;
+    }
+    float zero[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) zero[e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const int n = q0 + wave * 8 + st * 4 + sub;
+      if (n < a.N) {
+        const long row = (long)b * a.N + n;
+        row_store<C>(p_.z + row * C, l, zero);
+        row_store<C>(p_.y + row * C, l, zero);
+        if (p_.y_h) row_store<C>(p_.y_h + row * C, l, zero);
+        if (l == 0) { p_.mean[row] = 0.f; p_.rstd[row] = 0.f; }
+      }
+    }
+    return;
+  }
+  const int qload = min(qrow, a.N - 1);
+  bf16x8 qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) qf[ks] = load_row8(base + (size_t)qload * a.ld + h * HD + ks * 32 + g * 8, QSCALE2);
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const int bh = b * a.H + h;
+  const int ntiles = (len + 63) / 64;
+  const uint64_t drow = (uint64_t)((size_t)bh * a.N + qrow) << 14;
+  const uint32_t thresh_v = a.thresh;
+  f32x4 kreg[4], vreg[4];
+  DX_TILE_LOAD(QT, kreg, base, a.ld, a.D + h * HD, 0, a.N)
+  DX_TILE_LOAD(QT, vreg, base, a.ld, 2 * a.D + h * HD, 0, a.N)
+  for (int kt0 = 0; kt0 < ntiles; ++kt0) {
+    const int kbase = kt0 * 64;
+    __syncthreads();
+    DX_TILE_STORE(QT, kreg, Ks)
+    DX_TILE_STORE(QT, vreg, Vs)
+    __syncthreads();
+    if (kt0 + 1 < ntiles) {
+      DX_TILE_LOAD(QT, kreg, base, a.ld, a.D + h * HD, kbase + 64, a.N)
+      DX_TILE_LOAD(QT, vreg, base, a.ld, 2 * a.D + h * HD, kbase + 64, a.N)
+    }
+    f32x4 st[4];
+    float mx = -INFINITY;
+    const bool tail_tile = kbase + 64 > len;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) acc = DX_MFMA_1ST(row_frag(Ks, kt * 16 + r, ks, g), qf[ks], acc);
+      if (tail_tile) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (kbase + kt * 16 + g * 4 + e >= len) acc[e] = -INFINITY;
+      }
+      mx = dx_max2(mx, dx_max2(dx_max2(acc[0], acc[1]), dx_max2(acc[2], acc[3])));
+      st[kt] = acc;
+    }
+    mx = dx_max2(mx, __shfl_xor(mx, 16, 64));
+    mx = dx_max2(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = dx_max2(m_run, mx);
+    const bool rescale = __builtin_amdgcn_ballot_w64(m_new > m_run) != 0;
+    float ls = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      float pk[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pk[e] = DX_EXP2(st[kt][e] - m_new);
+        ls += pk[e];
+      }
+      if (a.thresh) dx_keep4(dx_rand64(a.seed, drow | (uint64_t)((kbase + kt * 16 + g * 4) >> 2)), thresh_v, pk, 0.f);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) st[kt][e] = pk[e];
+    }
+    ls += __shfl_xor(ls, 16, 64);
+    ls += __shfl_xor(ls, 32, 64);
+    if (rescale) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[dt][e] *= alpha;
+    }
+    l_run += ls;
+    m_run = m_new;
+    const bf16x8 p01 = pack_pair(st[0], st[1]), p23 = pack_pair(st[2], st[3]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4 acc = o[dt];
+      acc = DX_MFMA_2ND(tr_pair(Vs, 0 + g * 4, 16 + g * 4, dt * 16, lane), p01, acc);
+      acc = DX_MFMA_2ND(tr_pair(Vs, 32 + g * 4, 48 + g * 4, dt * 16, lane), p23, acc);
+      o[dt] = acc;
+    }
+  }
+  // ---- context: to HBM as before, and (the very same 16-bit values) into the LDS image the projection reads ----------------------------
+  {
+    const bool valid = qrow < len;
+    const float inv = valid ? (a.thresh ? a.inv_keep : 1.f) / l_run : 0.f;
+    const int crow = wq * 16 + r;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      bf16x4 c4;
+      c4[0] = (dx_h16)(o[dt][0] * inv); c4[1] = (dx_h16)(o[dt][1] * inv); c4[2] = (dx_h16)(o[dt][2] * inv); c4[3] = (dx_h16)(o[dt][3] * inv);
+      if (qrow < a.N) *reinterpret_cast<bf16x4*>(out + dt * 16 + g * 4) = c4;
+      const int slot = h * 8 + dt * 2 + (g >> 1);
+      *reinterpret_cast<bf16x4*>(Cs + crow * 256 + ((slot ^ (crow & 15)) << 4) + ((g & 1) << 3)) = c4;
+    }
+    if (qrow < a.N && g == 0) a.lse[((size_t)b * a.H + h) * a.N + qrow] = valid ? m_run + __log2f(l_run) : 0.f;
+  }
+  // the row pass's global reads go out before the projection (a workgroup is one dependent chain)
+  bool valid[2]; long rown[2];
+  float rv[2][E];
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const int n = q0 + wave * 8 + st * 4 + sub;
+    const bool inb = n < a.N;
+    valid[st] = inb && n < len;
+    rown[st] = inb ? (long)b * a.N + n : -1;
+#pragma unroll
+    for (int e = 0; e < E; ++e) rv[st][e] = 0.f;
+    if (valid[st] && p_.res) row_load<C>(p_.res + rown[st] * C, l, rv[st]);
+  }
+  float wv[E], bv[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) { wv[e] = p_.w[row_col<C>(l, e)]; bv[e] = p_.bias[row_col<C>(l, e)]; }
+  __syncthreads();                                      // the context image is complete; every K / V read has retired
+  // ---- out-projection: wave = column tile (16 tokens) wq x four of the eight 16-channel row blocks; K order 0..3 as proj_ln_fwd_kernel --------
+  {
+    const int tok = wq * 16 + r;
+    const bool live = q0 + tok < len;
+    if (__builtin_amdgcn_ballot_w64(live) != 0) {
+      bf16x8 xb[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) xb[ks] = *reinterpret_cast<const bf16x8*>(Cs + tok * 256 + (((ks * 4 + g) ^ (tok & 15)) << 4));
+      f32x4 acc[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[i] = p_.proj_bias ? *reinterpret_cast<const f32x4*>(p_.proj_bias + (h * 4 + i) * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 wa[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(p_.Wp + (size_t)((h * 4 + i) * 4 + ks) * 512 + lane * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = DX_MFMA_H16(wa[i], xb[ks], acc[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<f32x4*>(tile + tok * C + ((((h * 4 + i) * 4 + g) ^ (tok & 15)) << 2)) = acc[i];
+    }
+  }
+  __syncthreads();
+  // ---- row pass: exactly phase 2 of proj_ln_fwd_kernel, eight rows per wave in two steps of four -------------------------------------------
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const int lrow = wave * 8 + st * 4 + sub;
+    const long row = rown[st];
+    const bool inb = row >= 0, vld = valid[st];
+    float z[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) z[e] = 0.f;
+    if (vld) {
+#pragma unroll
+      for (int k = 0; k < RowVec<C>::K; ++k) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(tile + lrow * C + (((k * LPR + l) ^ (lrow & 15)) << 2));
+        z[k * 4 + 0] = t[0]; z[k * 4 + 1] = t[1]; z[k * 4 + 2] = t[2]; z[k * 4 + 3] = t[3];
+      }
+      if (p_.thresh_pre) {
+        float f[E];
+        row_dropout<C>(seed_pre, (uint64_t)row, l, p_.thresh_pre, p_.inv_keep_pre, f);
+#pragma unroll
+        for (int e = 0; e < E; ++e) z[e] *= f[e];
+      }
+#pragma unroll
+      for (int e = 0; e < E; ++e) z[e] += rv[st][e];
+    }
+    if (inb) row_store<C>(p_.z + row * C, l, z);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) s += z[e];
+    const float mu = row_sum<C>(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { const float d = z[e] - mu; q += d * d; }
+    const float rs = 1.0f / sqrtf(row_sum<C>(q) * (1.0f / C) + APL_LN_EPS);
+    if (inb && l == 0) { p_.mean[row] = vld ? mu : 0.f; p_.rstd[row] = vld ? rs : 0.f; }
+    float y[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int c = row_col<C>(l, e);
+      float t = (z[e] - mu) * rs * wv[e] + bv[e];
+      if (p_.film) t = p_.film[(size_t)b * p_.ld_film + c] * t + p_.film[(size_t)b * p_.ld_film + C + c];
+      y[e] = vld ? t : 0.f;
+    }
+    if (inb) {
+      row_store<C>(p_.y + row * C, l, y);
+      if (p_.y_h) row_store<C>(p_.y_h + row * C, l, y);
+    }
   }
 }
 
@@ -985,6 +1244,34 @@ int dx_attention_fwd(const void* qkvv, int ld, const int* lens, void* ctxv, int 
 }
 
 // dqkv (all three thirds, every row) from dctx; `delta` is scratch [B][H][N]
+// dx_attention_fwd (16-bit q/k/v and context, 2 heads, D = 128) followed by dx_proj_ln_fwd of dx_rows.hip on its result, in ONE launch with
+// bit-identical outputs: ctx / lse as dx_attention_fwd writes them; z = dropout(ctx W^T + proj_bias) + res, y = mask(FiLM(LayerNorm(z))), mean,
+// rstd and the optional 16-bit copy of y as dx_proj_ln_fwd writes them (halo 0).  Replaces model.py:165-191 per FFT block (forward).
+int dx_attention_proj_ln_fwd(const void* qkv, int ld, const int* lens, void* ctx, int ldc, float* lse, int B, int N, int H, int D,
+                             uint64_t seed, const uint64_t* seed_offset, float p_drop,
+                             const void* Wpack, const float* proj_bias, float* z, const float* res, const float* w, const float* bias,
+                             const float* film, int ld_film, float* y, float* mean, float* rstd, uint64_t seed_pre, float p_pre,
+                             void* y_bf16_copy, void* stream) {
+  if (int rc = check_common("dx_attention_proj_ln_fwd", qkv, ld, B, N, H, D)) return rc;
+  DX_REQUIRE(H == 2 && D == 128 && (ld % 8) == 0 && (ldc % 8) == 0 && ldc >= D, "dx_attention_proj_ln_fwd: 2 heads x 64, 16-bit rows (ld, ldc multiples of 8)");
+  DX_REQUIRE(lens && ctx && lse && Wpack && z && w && bias && y && mean && rstd, "dx_attention_proj_ln_fwd: null pointer");
+  DX_REQUIRE(((uintptr_t)ctx % 16) == 0 && ((uintptr_t)Wpack % 16) == 0 && ((uintptr_t)z % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+             (!res || ((uintptr_t)res % 16) == 0), "dx_attention_proj_ln_fwd: pointers must be 16-byte aligned");
+  DX_REQUIRE(p_drop >= 0.f && p_drop < 1.f && p_pre >= 0.f && p_pre < 1.f, "dx_attention_proj_ln_fwd: dropout p out of range");
+  DX_REQUIRE(!film || ld_film >= 256, "dx_attention_proj_ln_fwd: ld_film too small");
+  AttnProjLnArgs k{};
+  k.at = AttnArgs{(const float*)qkv, ld, lens, (float*)ctx, ldc, lse, B, N, H, D, seed, (uint32_t)lrintf(p_drop * 65536.f), 1.f / (1.f - p_drop), seed_offset, nullptr, 0};
+  k.Wp = (const dx_h16*)Wpack; k.proj_bias = proj_bias; k.z = z; k.res = res; k.w = w; k.bias = bias; k.film = film; k.ld_film = ld_film;
+  k.y = y; k.y_h = (dx_h16*)y_bf16_copy; k.mean = mean; k.rstd = rstd;
+  k.seed_pre = seed_pre; k.thresh_pre = (uint32_t)lrintf(p_pre * 65536.f); k.inv_keep_pre = 1.f / (1.f - p_pre);
+  hipStream_t s = (hipStream_t)stream;
+  dx_prof_begin(DX_PROF_ATTN_FWD, s);
+  hipLaunchKernelGGL(attn_proj_ln_fwd_kernel, dim3(8 * dx_cdiv(N, 64) * dx_cdiv(B, 8)), dim3(512), 0, s, k);
+  dx_prof_end(DX_PROF_ATTN_FWD, s);
+  DX_LAUNCH_CHECK("dx_attention_proj_ln_fwd");
+  return DX_OK;
+}
+
 int dx_attention_bwd(const void* qkvv, int ld, const void* ctxv, const void* dctxv, int ldc, const float* lse, float* delta,
                      const int* lens, void* dqkvv, int ldg, int B, int N, int H, int D, uint64_t seed, const uint64_t* seed_offset, float p_drop, int bf16,
                      int qkv_bf16, int dqkv_bf16, int ctx_bf16, const int* order, void* stream) {

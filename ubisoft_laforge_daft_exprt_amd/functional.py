@@ -179,17 +179,23 @@ class FFTBlockFn(torch.autograd.Function):
         qkv = qkv_pre if qkv_pre is not None else \
             ops.conv_gemm(x, packs['in'], in_b, lens=L, halo=0, out_dtype=hd, prec=prec)     # bf16 mode: attention reads bf16 q/k/v
         so = rt.seed_offset                        # device scalar added to the seeds (graph replays), or None
-        att, lse = ops.attention_fwd(qkv, lens.i32, heads, s_attn, p_attn, prec=prec, seed_offset=so, ctx_dtype=hd, order=lens.order)   # 16-bit modes: 16-bit context
         sh = ops.gemm_shadow(prec)                 # bf16 mode: GEMM operands also exist as bf16 copies written by their producers
-        if ops.proj_ln_applies(att, packs['out'], prec):   # out-projection + dropout + residual + LayerNorm: one launch, z1 straight from LDS
-            z1, y1, mean1, rstd1, *rest = ops.proj_ln_fwd(att, packs['out'], out_b, x, ln1_w, ln1_b, None, lens.i32, seed_pre=s_ln1, p_pre=p_attn,
-                                                         shadow=sh, seed_offset=so, prec=prec)
+        if ops.attn_proj_ln_applies(qkv, heads, packs['out'], prec, lens.order):
+            # attention of both heads + out-projection + dropout + residual + LayerNorm in ONE launch (same bits as the two launches below)
+            att, lse, z1, y1, mean1, rstd1, *rest = ops.attn_proj_ln_fwd(qkv, lens.i32, heads, s_attn, p_attn, packs['out'], out_b, x, ln1_w, ln1_b, None,
+                                                                         seed_pre=s_ln1, p_pre=p_attn, shadow=sh, seed_offset=so, prec=prec)
             y1g = rest[0] if sh else y1
         else:
-            z1 = ops.conv_gemm(att, packs['out'], out_b, lens=L, halo=0, prec=prec)
-            ln1 = ops.ln_fwd(z1, x, ln1_w, ln1_b, None, lens.i32, seed_pre=s_ln1, p_pre=p_attn, shadow=sh, seed_offset=so, prec=prec)
-            y1, mean1, rstd1 = ln1[:3]
-            y1g = ln1[3] if sh else y1             # the copy the GEMMs read
+            att, lse = ops.attention_fwd(qkv, lens.i32, heads, s_attn, p_attn, prec=prec, seed_offset=so, ctx_dtype=hd, order=lens.order)   # 16-bit modes: 16-bit context
+            if ops.proj_ln_applies(att, packs['out'], prec):   # out-projection + dropout + residual + LayerNorm: one launch, z1 straight from LDS
+                z1, y1, mean1, rstd1, *rest = ops.proj_ln_fwd(att, packs['out'], out_b, x, ln1_w, ln1_b, None, lens.i32, seed_pre=s_ln1, p_pre=p_attn,
+                                                             shadow=sh, seed_offset=so, prec=prec)
+                y1g = rest[0] if sh else y1
+            else:
+                z1 = ops.conv_gemm(att, packs['out'], out_b, lens=L, halo=0, prec=prec)
+                ln1 = ops.ln_fwd(z1, x, ln1_w, ln1_b, None, lens.i32, seed_pre=s_ln1, p_pre=p_attn, shadow=sh, seed_offset=so, prec=prec)
+                y1, mean1, rstd1 = ln1[:3]
+                y1g = ln1[3] if sh else y1             # the copy the GEMMs read
         fused = ops.ff_pair_applies(y1g, packs['c1'], packs['c2'], prec)
         y2 = qkv_next = hmask = None
         if fused and ops._FF_LN:   # ... and the block's second LayerNorm on the output tile while it is still in LDS

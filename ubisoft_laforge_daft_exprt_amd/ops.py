@@ -609,6 +609,38 @@ def proj_ln_applies(x, pack: PackedWeight, prec) -> bool:
 _PROJ_LN = os.environ.get('DX_PROJ_LN', '1') != '0'
 
 
+_ATTN_PROJ_LN = os.environ.get('DX_ATTN_PROJ_LN', '1') != '0'
+
+
+def attn_proj_ln_applies(qkv, heads, pack: PackedWeight, prec, order=None) -> bool:
+    """Attention forward + out-projection + LayerNorm in one launch: the 16-bit modes at the FFT block's shape (2 heads x 64, 16-bit q/k/v)."""
+    return (_ATTN_PROJ_LN and _PROJ_LN and prec in _H16 and qkv.dtype == _H16[prec] and qkv.dim() == 3 and qkv.shape[2] == 384 and heads == 2
+            and order is None and pack.taps == 1 and pack.cin == 128 and pack.cout == 128)
+
+
+def attn_proj_ln_fwd(qkv, lens, heads, seed, p_drop, pack: PackedWeight, proj_bias, res, w, b, film, *, seed_pre=0, p_pre=0.0, shadow=False,
+                     seed_offset=None, prec=None):
+    """attention_fwd (16-bit context) + proj_ln_fwd on it, one launch, the same bits.  Returns (ctx, lse, z, y, mean, rstd[, y_16bit])."""
+    B, N, D3 = qkv.shape
+    D = D3 // 3
+    prec = prec or pack.rt.precision
+    _check_h16(prec, qkv)
+    h16 = _H16[prec]
+    ctx = torch.empty(B, N, D, dtype=h16, device=qkv.device)
+    lse = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device)
+    z = torch.empty(B, N, D, dtype=torch.float32, device=qkv.device)
+    y = torch.empty_like(z)
+    y_h = torch.empty(B, N, D, dtype=h16, device=qkv.device) if shadow else None
+    mean = torch.empty(B, N, dtype=torch.float32, device=qkv.device)
+    rstd = torch.empty(B, N, dtype=torch.float32, device=qkv.device)
+    img = pack.image(prec)
+    _log(pack, ('gemm', B * N, N, pack.cin, pack.cout, 1))
+    _fn('dx_attention_proj_ln_fwd', prec)(_p(qkv), _rows(qkv), _p(lens), _p(ctx), D, _p(lse), B, N, heads, D, seed, _p(seed_offset), float(p_drop),
+                                          _p(img.fwd), _p(proj_bias), _p(z), _p(res), _p(w), _p(b), _p(film), 0 if film is None else film.stride(0),
+                                          _p(y), _p(mean), _p(rstd), seed_pre, float(p_pre), _p(y_h), _stream())
+    return (ctx, lse, z, y, mean, rstd, y_h) if shadow else (ctx, lse, z, y, mean, rstd)
+
+
 def proj_ln_fwd(x, pack: PackedWeight, proj_bias, res, w, b, film, lens, *, seed_pre=0, p_pre=0.0, halo=0, shadow=False, seed_offset=None, prec=None):
     """z = dropout(x W^T + proj_bias) + res; y = mask(FiLM(LN(z))) in one launch.  Returns (z, y, mean, rstd[, y_16bit])."""
     B, N, C = x.shape

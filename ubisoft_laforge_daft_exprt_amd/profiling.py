@@ -115,6 +115,11 @@ def price(name, a, geom: Geometry):
         flops = 2.0 * 3 * (a['M'] * 256 + 2 * 256 * 256 + 256) * rows
         byt = rows * (a['M'] * 4 + 4 + 96 + (a['M'] * 8 if name.endswith('bwd') else 0))       # mel / pp (dpp) / sign bits; backward: dmel read + written
         return ('pitch_chain<fwd>' if name.endswith('fwd') else 'pitch_chain<bwd>'), 'mfma', flops, byt
+    if name == 'dx_attention_proj_ln_fwd':               # attn_fwd + proj_ln_fwd in one launch: both products, the 128 x 128 projection, the row pass's bytes
+        rows, pairs = geom.rows(a['B'], a['N']), geom.pairs(a['B'], a['N'])
+        D, H = a['D'], a['H']
+        byt = rows * (3 * D * 2 + D * 2 + H * 4) + rows * (128 * (4 + 4 + (4 if has('res') else 0) + (2 if has('y_bf16_copy') else 0)) + 8) + 128 * 128 * 2
+        return 'attn_fwd+proj_ln', 'mfma', 4.0 * pairs * D + 2.0 * rows * 128 * 128, byt
     if name == 'dx_ln_fwd':
         rows = geom.rows(a['B'], a['N'], has('lens'))
         C, ab = a['C'], (2 if a['io_bf16'] else 4)
