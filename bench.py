@@ -81,7 +81,7 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--precision', default='bf16', choices=['f32', 'bf16', 'fp16'])
     ap.add_argument('--config', default='C2', choices=['C1', 'C2', 'C5'])
