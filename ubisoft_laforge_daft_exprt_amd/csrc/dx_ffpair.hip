@@ -96,6 +96,7 @@ struct FFPairArgs {
   // "hidden value (column tile j = NJ-1 - k/4, channel 3 - k%4 of the lane's four) was > 0"; [B * tiles][F / 128][4 waves][2][64 lanes]
   unsigned* hmask;
   int slice_skew;                    // 1: workgroup w starts its walk over the hidden slices at slice w % nslices (see the kernel)
+  int dz_lds;                        // 1 (block backward with the LayerNorm prologue): dz2 waits for the epilogue in LDS behind the images instead of in Y (see the prologue)
   unsigned long long* stamps;        // diagnostic builds (-DDX_FFPAIR_STAMPS, tools/ffpair_stamps.py) only: [workgroup][role][16] s_memtime values
 };
 
@@ -145,6 +146,11 @@ __global__ __launch_bounds__(512, 2) void ff_pair_kernel(const FFPairArgs a) {
   unsigned char* const Xs = smem;
   unsigned char* const Hs0 = smem + FP_IMG;
   unsigned char* const Hs1 = smem + 2 * FP_IMG;
+  // The block backward's prologue produces dz2 (the residual-branch gradient) and its epilogue adds the pair's result to it: through Y that is
+  // 512 B/token written and 512 B/token read back in the two HBM-bound, matrix-idle ends of the kernel.  The rows that fit behind the three
+  // images (126-token tiles: 112 of 126 rows = 56 KB, 157 KB of LDS in all; 62-token tiles: all rows) wait there instead; the rest go through Y.
+  constexpr int DZ_ROWS = NJ == 8 ? 112 : FP_TOK;
+  float* const dzs = (a.lnp_w && a.dz_lds) ? reinterpret_cast<float*>(smem + 3 * FP_IMG) : nullptr;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -336,8 +342,13 @@ __global__ __launch_bounds__(512, 2) void ff_pair_kernel(const FFPairArgs a) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) dz[e] = rsv[it] * (g[e] - s1 - xh[e] * s2);
       if (owned) {
-        *reinterpret_cast<f32x4*>(a.Y + grow * a.ldy + q * 8) = f32x4{dz[0], dz[1], dz[2], dz[3]};
-        *reinterpret_cast<f32x4*>(a.Y + grow * a.ldy + q * 8 + 4) = f32x4{dz[4], dz[5], dz[6], dz[7]};
+        if (dzs && row - 2 < DZ_ROWS) {
+          *reinterpret_cast<f32x4*>(dzs + (row - 2) * 128 + q * 8) = f32x4{dz[0], dz[1], dz[2], dz[3]};
+          *reinterpret_cast<f32x4*>(dzs + (row - 2) * 128 + q * 8 + 4) = f32x4{dz[4], dz[5], dz[6], dz[7]};
+        } else {
+          *reinterpret_cast<f32x4*>(a.Y + grow * a.ldy + q * 8) = f32x4{dz[0], dz[1], dz[2], dz[3]};
+          *reinterpret_cast<f32x4*>(a.Y + grow * a.ldy + q * 8 + 4) = f32x4{dz[4], dz[5], dz[6], dz[7]};
+        }
       }
       if (a.lnp_thresh) {
         float f[8];
@@ -750,7 +761,8 @@ __global__ __launch_bounds__(512, 2) void ff_pair_kernel(const FFPairArgs a) {
       const int row = (tid >> 5) + k * 16, n = n0 + row;
       const bool valid = row < len_cols && n < len_b;
       const size_t grow = (size_t)b * a.N + n;
-      oldv[k] = valid ? *reinterpret_cast<const f32x4*>(a.Y + grow * a.ldy + s * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (dzs && row < DZ_ROWS) oldv[k] = valid ? *reinterpret_cast<const f32x4*>(dzs + row * 128 + s * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      else oldv[k] = valid ? *reinterpret_cast<const f32x4*>(a.Y + grow * a.ldy + s * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
       zv[k] = valid ? *reinterpret_cast<const f32x4*>(a.lnb_z + grow * 128 + s * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
       muv[k] = valid ? a.lnb_mean[grow] : 0.f;
       rsv[k] = valid ? a.lnb_rstd[grow] : 0.f;
@@ -928,13 +940,18 @@ static int ff_pair_launch(const void* X, int ldx, const void* Wa, const void* Wb
 #ifdef DX_FFPAIR_STAMPS
   a.stamps = g_ffpair_stamps;
 #endif
+  // LDS: the three images, + (block backward with the LayerNorm prologue) the dz2 rows that wait for the epilogue
+  constexpr int DZ8 = 112 * 512, DZ4 = FP<4>::TOK * 512;
+  static const int dz_env = getenv("DX_FF_DZ_LDS") ? atoi(getenv("DX_FF_DZ_LDS")) : 1;
+  a.dz_lds = dz_env && a.lnp_w != nullptr;
+  const int lds8 = 3 * FP<8>::IMG + (a.dz_lds ? DZ8 : 0), lds4 = 3 * FP<4>::IMG + (a.dz_lds ? DZ4 : 0);
   static bool configured = false;
   if (!configured) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_pair_kernel<true, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP<8>::IMG);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_pair_kernel<true, false, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP<8>::IMG);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_pair_kernel<true, false, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP<4>::IMG);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_pair_kernel<true, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP<8>::IMG + DZ8);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_pair_kernel<true, false, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP<8>::IMG + DZ8);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_pair_kernel<true, false, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP<4>::IMG + DZ4);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_pair_kernel<false, true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP<8>::IMG);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_pair_kernel<true, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP<4>::IMG);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_pair_kernel<true, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP<4>::IMG + DZ4);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_pair_kernel<false, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * FP<4>::IMG);
     configured = true;
   }
@@ -950,12 +967,12 @@ static int ff_pair_launch(const void* X, int ldx, const void* Wa, const void* Wb
   hipStream_t s = (hipStream_t)stream;
   dx_prof_begin(DX_PROF_CONV_GEMM, s);
   if (nj == 8) {
-    if (aux && hmask) hipLaunchKernelGGL((ff_pair_kernel<true, false, 8, true>), dim3(B * dx_cdiv(N, FP<8>::TOK)), dim3(512), 3 * FP<8>::IMG, s, a);
-    else if (aux) hipLaunchKernelGGL((ff_pair_kernel<true, false, 8>), dim3(B * dx_cdiv(N, FP<8>::TOK)), dim3(512), 3 * FP<8>::IMG, s, a);
+    if (aux && hmask) hipLaunchKernelGGL((ff_pair_kernel<true, false, 8, true>), dim3(B * dx_cdiv(N, FP<8>::TOK)), dim3(512), lds8, s, a);
+    else if (aux) hipLaunchKernelGGL((ff_pair_kernel<true, false, 8>), dim3(B * dx_cdiv(N, FP<8>::TOK)), dim3(512), lds8, s, a);
     else hipLaunchKernelGGL((ff_pair_kernel<false, true, 8>), dim3(B * dx_cdiv(N, FP<8>::TOK)), dim3(512), 3 * FP<8>::IMG, s, a);
   } else {
-    if (aux && hmask) hipLaunchKernelGGL((ff_pair_kernel<true, false, 4, true>), dim3(B * dx_cdiv(N, FP<4>::TOK)), dim3(512), 3 * FP<4>::IMG, s, a);
-    else if (aux) hipLaunchKernelGGL((ff_pair_kernel<true, false, 4>), dim3(B * dx_cdiv(N, FP<4>::TOK)), dim3(512), 3 * FP<4>::IMG, s, a);
+    if (aux && hmask) hipLaunchKernelGGL((ff_pair_kernel<true, false, 4, true>), dim3(B * dx_cdiv(N, FP<4>::TOK)), dim3(512), lds4, s, a);
+    else if (aux) hipLaunchKernelGGL((ff_pair_kernel<true, false, 4>), dim3(B * dx_cdiv(N, FP<4>::TOK)), dim3(512), lds4, s, a);
     else hipLaunchKernelGGL((ff_pair_kernel<false, true, 4>), dim3(B * dx_cdiv(N, FP<4>::TOK)), dim3(512), 3 * FP<4>::IMG, s, a);
   }
   dx_prof_end(DX_PROF_CONV_GEMM, s);
